@@ -1,0 +1,182 @@
+/*
+ * scream_hip.h -- C ABI of libscream_hip.so: the MI355X (gfx950) kernels behind the
+ * SCREAM registration hot path.
+ *
+ * The reference (xujiabo/SCREAM) has no FFI/operator layer: its hot path is stock ATen
+ * calls made from Python.  Each entry point below therefore cites the reference
+ * *call site* (file:line under the reference checkout) whose arithmetic it replaces;
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add at that site.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     unless the name ends in _host; kernels never allocate and keep no global state;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - returns 0 on success, a negative SCREAM_E* code on a rejected argument (checked on
+ *     the host before any launch), or the positive hipError_t of a failed launch;
+ *   - all floating point is IEEE fp32 (fp64 only inside the 3x3 Kabsch solve);
+ *   - "rows" are points/tokens.  A *packed batch* holds several clouds back to back, each
+ *     cloud starting on a 128-row boundary (SCREAM_ROW_TILE) and zero-padded to one, so a
+ *     128-row tile never spans two clouds.
+ */
+#ifndef SCREAM_HIP_H
+#define SCREAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCREAM_ROW_TILE 128
+#define SCREAM_D_MODEL 256
+#define SCREAM_NHEAD 8
+#define SCREAM_HEAD_DIM 32
+#define SCREAM_KV_CHUNK 256 /* tokens per partial K^T V reduction */
+
+#define SCREAM_EINVAL (-1) /* bad size / alignment / NULL pointer */
+#define SCREAM_EUNSUPPORTED (-2) /* shape outside what the gfx950 kernels are built for */
+
+/* GEMM epilogues (models/transformer.py:79-88, models/pointnet.py:27-33) */
+enum {
+    SCREAM_EPI_NONE = 0,      /* C = A W^T */
+    SCREAM_EPI_ELU1 = 1,      /* columns < n_act: elu(x)+1 (transformer.py:7-8,28-29); rest plain */
+    SCREAM_EPI_RELU = 2,      /* relu (transformer.py:66) */
+    SCREAM_EPI_BIAS_RELU = 3, /* + bias, relu (pointnet.py:28-31) */
+    SCREAM_EPI_RES_LN = 4     /* LayerNorm(C + residual) * gamma + beta, N == 256 (transformer.py:84,88) */
+};
+
+/* Library / build identification: "scream_hip gfx950 <abi>"; abi bumps on any signature change. */
+const char* scream_version(void);
+int scream_abi_version(void);
+
+/* ---- A2/A4/A6: C[M,N] = epilogue(A[M,K] . W[N,K]^T), fp32-input MFMA (v_mfma_f32_32x32x2_f32).
+ * Replaces torch.nn.Linear / Conv1d(k=1) at models/transformer.py:79-81,83,87 and
+ * models/pointnet.py:60.  M % 128 == 0, N % 256 == 0, K % 32 == 0, lda/ldc/ldr in floats. */
+int scream_gemm_f32(const float* A, int64_t lda, const float* W, float* C, int64_t ldc,
+                    int64_t M, int32_t N, int32_t K, int32_t epilogue, int32_t n_act,
+                    const float* bias, const float* residual, int64_t ldr,
+                    const float* gamma, const float* beta, void* stream);
+
+/* ---- A1: feats = LayerNorm(PE_sine(xyz) + W_e (xyz - center[cloud]) + b_e)
+ * Replaces models/pointnet.py:45-48 (+ models/transformer.py:157-179).  xyz [rows,3] packed;
+ * tile_cloud[rows/128] gives the cloud of each 128-row tile; center [n_clouds,3] (zeros for
+ * target clouds); dim_t [84] is the host-computed frequency table of transformer.py:168-170. */
+int scream_pe_embed_ln(const float* xyz, const int32_t* tile_cloud, const float* center,
+                       const float* dim_t, const float* emb_w, const float* emb_b,
+                       const float* gamma, const float* beta, float* feats, int64_t rows,
+                       void* stream);
+
+/* ---- A3 (reduce): per key cloud and head, KV = sum_s K[s]^T (V[s]/S), Ksum = sum_s K[s]
+ * Replaces models/transformer.py:38-41 (values / v_length, the "nshd,nshv->nhdv" einsum, K.sum).
+ * Kf/Vf point at column 0 of the (elu+1)-mapped keys / raw values, row stride ld floats, row 0 =
+ * packed row `row_base`.  cloud_row0/cloud_len [n_clouds] (int32, absolute packed rows / true lengths).
+ * Processes clouds [cloud_begin, cloud_begin + n_kv).  partial is scratch of
+ * n_kv * max_chunks * 8 * 33 * 32 floats; kv_out [n_clouds][8][33][32]: rows 0-31 of a head hold KV^T
+ * ([v][d], d contiguous -- the layout scream_attn_apply stages into LDS), row 32 holds Ksum[d]. */
+int scream_kv_reduce(const float* Kf, const float* Vf, int64_t ld, int64_t row_base,
+                     const int32_t* cloud_row0, const int32_t* cloud_len, int32_t cloud_begin,
+                     int32_t n_kv, int32_t max_chunks, float* partial, float* kv_out, void* stream);
+
+/* ---- A3 (apply): out[l,h,:] = (Q[l,h,:] . KV[h]) * 1/(Q[l,h,:].Ksum[h] + 1e-6) * S
+ * Replaces models/transformer.py:41-42.  Qf [rows, ldq] (elu+1 mapped), kv as written by
+ * scream_kv_reduce; the key cloud of query tile t is tile_cloud[t] + kv_cloud_offset. */
+int scream_attn_apply(const float* Qf, int64_t ldq, const float* kv, const int32_t* tile_cloud,
+                      int32_t kv_cloud_offset, const int32_t* cloud_len, float* out, int64_t ldo,
+                      int64_t rows, void* stream);
+
+/* ---- A6 (head): out[rows,3] = X[rows,256] . W[3,256]^T + b.  models/pointnet.py:32,60 */
+int scream_coor_head(const float* X, const float* W, const float* b, float* out, int64_t rows,
+                     void* stream);
+
+/* ---- Whole forward pass of PointTransformer over a packed batch (A1-A6).
+ * Replaces models/pointnet.py:38-60 for B pairs at once (the reference asserts B == 1, :39-40). */
+typedef struct {
+    const float* wqkv; /* [768,256]: rows 0-255 q_proj, 256-511 k_proj, 512-767 v_proj */
+    const float* wm;   /* merge [256,256] */
+    const float* w1;   /* mlp.0 [1024,256] */
+    const float* w2;   /* mlp.2 [256,1024] */
+    const float* g1; const float* b1; /* norm1 */
+    const float* g2; const float* b2; /* norm2 */
+} scream_layer_t;
+
+typedef struct {
+    int32_t n_self;  /* stem layers (models/pointnet.py:18-20) */
+    int32_t n_cross; /* (self, cross) layer pairs (:22-25) */
+    const float* dim_t; /* [84] */
+    const float* emb_w; const float* emb_b; /* [256,3], [256] */
+    const float* pre_g; const float* pre_b; /* pre_norm */
+    const scream_layer_t* layers_host; /* HOST array: n_self stem layers, then cross.0, cross.1.layer, ... */
+    const float* c0_w; const float* c0_b; /* coor_mlp.0 [256,256],[256] */
+    const float* c2_w; const float* c2_b; /* coor_mlp.2 */
+    const float* c4_w; const float* c4_b; /* coor_mlp.4 [3,256],[3] */
+} scream_model_t;
+
+typedef struct {
+    int32_t n_pairs;     /* B; clouds 0..B-1 are the sources, B..2B-1 the targets */
+    int64_t rows_src;    /* packed rows of all source clouds (multiple of 128) */
+    int64_t rows_total;  /* sources then targets (multiple of 128) */
+    int32_t max_chunks;  /* max over clouds of ceil(len / SCREAM_KV_CHUNK) */
+    const float* xyz;          /* [rows_total,3], zero in padding rows */
+    const float* center;       /* [2B,3]: src_center per source cloud, zeros for targets */
+    const int32_t* tile_cloud; /* [rows_total/128] */
+    const int32_t* cloud_row0; /* [2B] */
+    const int32_t* cloud_len;  /* [2B] */
+} scream_batch_t;
+
+/* Bytes of scratch scream_forward needs for this batch geometry. */
+int64_t scream_forward_workspace_bytes(int64_t rows_src, int64_t rows_total, int32_t n_pairs,
+                                       int32_t max_chunks);
+
+/* src_pred [rows_src,3] (padding rows hold don't-care values).  If feats_out != NULL the final
+ * source features [rows_src,256] are copied there (test hook). */
+int scream_forward(const scream_model_t* model, const scream_batch_t* batch, void* workspace,
+                   int64_t workspace_bytes, float* src_pred, float* feats_out, void* stream);
+
+/* ---- A7: thresholded 1-NN of every query point in its pair's target cloud.
+ * Replaces square_distance(src_pred / s, tgt / s)[0].min(dim=1) and the threshold compare at
+ * evaluate_3d_match.py:94-95 (also models/pointnet.py:71-72, evaluate_kitti.py:53-54) without
+ * materialising the N x M matrix.  Bit-exact fp32 arithmetic of utils.py:72-78 as torch-CPU
+ * executes it: a = x / fp32(s) (IEEE divide); dot = fma(a2,b2,fma(a1,b1,a0*b0));
+ * |a|^2 = (a0^2 + a1^2) + a2^2; d = ((-2 dot) + |a|^2) + |b|^2; ties -> lowest target index.
+ * One launch set covers n_pairs pairs.  query/ref are packed [rows,3]; q_row0/q_len, r_row0/r_len
+ * [n_pairs] int32 (device); s [n_pairs] fp32 (device).  Outputs are indexed by packed query row:
+ * idx (int32, index inside the pair's target cloud; -1 in rows outside any cloud), dmin (fp32),
+ * valid (uint8: dmin < thresh).  Scratch: ref_prep 4 floats per ref row, keys one uint64 per query row. */
+int scream_nn_search(const float* query, const float* ref, const int32_t* q_row0,
+                     const int32_t* q_len, const int32_t* r_row0, const int32_t* r_len,
+                     const float* s, int32_t n_pairs, int32_t max_q_len, int32_t max_r_len,
+                     int64_t q_rows_total, int64_t r_rows_total, float thresh, float* ref_prep,
+                     uint64_t* keys, int32_t* idx, float* dmin, uint8_t* valid, void* stream);
+
+/* Dense utils.square_distance (utils.py:72-78): out[B,N,M] = -2 src.dst^T + |src|^2 + |dst|^2 with the
+ * rounding sequence above.  API compatibility only -- the hot path uses scream_nn_search. */
+int scream_square_distance(const float* src, const float* dst, float* out, int32_t B, int32_t N,
+                           int32_t M, void* stream);
+
+/* ---- A8 + A9 (+ A10): correspondence gather fused into the weighted Kabsch solve.
+ * Replaces evaluate_3d_match.py:96-101 and utils.py:138-178 for n_pairs pairs in one launch:
+ *   A_n = src[n] / s + c, B_n = ref[idx[n]] / s + c for every n with valid[n] (idx == NULL: B row = n,
+ *   the corr="src_pred" branch of evaluate_3d_match.py:99-101); centroids sum/(K + 1e-6);
+ *   H = sum (A-cA)(B-cB)^T; 3x3 SVD by one-sided Jacobi in registers (fp64), R = V diag(1,1,det(V U^T)) U^T,
+ *   t = cB - R cA.  K == 0 gives the identity, as torch.svd of a zero matrix does.
+ * T_out [n_pairs,16] row-major 4x4; n_corr [n_pairs] (int32) = K.  c is [n_pairs,3]. */
+int scream_kabsch_corr(const float* src, const float* ref, const int32_t* src_row0,
+                       const int32_t* src_len, const int32_t* ref_row0, const int32_t* idx,
+                       const uint8_t* valid, const float* s, const float* c, int32_t n_pairs,
+                       float* T_out, int32_t* n_corr, void* stream);
+
+/* Drop-in for utils.rigid_transform_3d (utils.py:138): A, B [bs,K,3] dense, w [bs,K] or NULL.
+ * Weights below weight_threshold count as 0 (utils.py:151).  T_out [bs,16]. */
+int scream_rigid_transform_3d(const float* A, const float* B, const float* w,
+                              float weight_threshold, int32_t bs, int32_t K, float* T_out,
+                              void* stream);
+
+/* ---- A10: RE [deg] = acos(clamp((tr(Rp^T Rg) - 1)/2)) * 180/pi, TE = |tp - tg| (utils.py:181-189).
+ * T_pred, T_gt [n,16]; re, te [n]. */
+int scream_transformation_error(const float* T_pred, const float* T_gt, int32_t n, float* re,
+                                float* te, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCREAM_HIP_H */

@@ -1,0 +1,138 @@
+// A1-A6: the PointTransformer layer schedule (models/pointnet.py:45-60) over a packed batch of pairs.
+//
+// The whole forward is one host call that enqueues every kernel on the caller's stream (no allocation,
+// no synchronisation, graph-capturable).  Rows are packed [all source clouds | all target clouds], so
+//   * the 6 stem layers, which the reference applies to tgt and then src with the SAME weights
+//     (pointnet.py:50-52), run as one launch set over every row of every cloud of every pair;
+//   * the cross stage (pointnet.py:53-57) runs over the source prefix only, the target features stay
+//     frozen in the rows the stem left them in.
+#include "common.h"
+
+namespace {
+
+constexpr int D = SCREAM_D_MODEL;
+constexpr int KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;
+
+struct Workspace {
+    float *x0, *x1, *qkv, *att, *m1, *hid, *kvp, *kv;
+    int64_t bytes;
+};
+
+Workspace carve(void* base, int64_t rows_total, int32_t n_pairs, int32_t max_chunks) {
+    Workspace w;
+    float* p = reinterpret_cast<float*>(base);
+    auto take = [&](int64_t n) {
+        float* r = p;
+        p += (n + 63) / 64 * 64;  // keep every buffer 256-byte aligned
+        return r;
+    };
+    w.x0 = take(rows_total * D);
+    w.x1 = take(rows_total * D);
+    w.qkv = take(rows_total * 3 * D);
+    w.att = take(rows_total * D);
+    w.m1 = take(rows_total * D);
+    w.hid = take(rows_total * 4 * D);
+    w.kvp = take((int64_t)2 * n_pairs * max_chunks * SCREAM_NHEAD * KV_ELEMS);
+    w.kv = take((int64_t)2 * n_pairs * SCREAM_NHEAD * KV_ELEMS);
+    w.bytes = (p - reinterpret_cast<float*>(base)) * (int64_t)sizeof(float);
+    return w;
+}
+
+#define TRY(call)                 \
+    do {                          \
+        int rc_ = (call);         \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+// merge + norm1 + FFN + norm2 (models/transformer.py:83-88); x is the block input (residual of BOTH norms).
+int mha_tail(const scream_layer_t& L, const Workspace& w, const float* x, float* y, int64_t rows, void* st) {
+    TRY(scream_gemm_f32(w.att, D, L.wm, w.m1, D, rows, D, D, SCREAM_EPI_RES_LN, 0, nullptr, x, D, L.g1, L.b1, st));
+    TRY(scream_gemm_f32(w.m1, D, L.w1, w.hid, 4 * D, rows, 4 * D, D, SCREAM_EPI_RELU, 0, nullptr, nullptr, 0, nullptr,
+                        nullptr, st));
+    TRY(scream_gemm_f32(w.hid, 4 * D, L.w2, y, D, rows, D, 4 * D, SCREAM_EPI_RES_LN, 0, nullptr, x, D, L.g2, L.b2, st));
+    return 0;
+}
+
+// Self attention over rows [0, rows) whose clouds are [0, n_clouds)  (transformer.py:74-90 with q = k = v).
+int mha_self(const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x, float* y,
+             int64_t rows, int32_t n_clouds, void* st) {
+    TRY(scream_gemm_f32(x, D, L.wqkv, w.qkv, 3 * D, rows, 3 * D, D, SCREAM_EPI_ELU1, 2 * D, nullptr, nullptr, 0,
+                        nullptr, nullptr, st));
+    TRY(scream_kv_reduce(w.qkv + D, w.qkv + 2 * D, 3 * D, 0, b.cloud_row0, b.cloud_len, 0, n_clouds, b.max_chunks,
+                         w.kvp, w.kv, st));
+    TRY(scream_attn_apply(w.qkv, 3 * D, w.kv, b.tile_cloud, 0, b.cloud_len, w.att, D, rows, st));
+    return mha_tail(L, w, x, y, rows, st);
+}
+
+// Cross attention: queries from the source rows, keys/values from the frozen target rows (transformer.py:130).
+int mha_cross(const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x_src,
+              const float* x_tgt, float* y, void* st) {
+    const int64_t rs = b.rows_src, rt = b.rows_total - b.rows_src;
+    float* qb = w.qkv;             // [rs, 256]
+    float* kvb = w.qkv + rs * D;   // [rt, 512]
+    TRY(scream_gemm_f32(x_src, D, L.wqkv, qb, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, 0, nullptr, nullptr, st));
+    TRY(scream_gemm_f32(x_tgt, D, L.wqkv + (int64_t)D * D, kvb, 2 * D, rt, 2 * D, D, SCREAM_EPI_ELU1, D, nullptr,
+                        nullptr, 0, nullptr, nullptr, st));
+    TRY(scream_kv_reduce(kvb, kvb + D, 2 * D, rs, b.cloud_row0, b.cloud_len, b.n_pairs, b.n_pairs, b.max_chunks, w.kvp,
+                         w.kv, st));
+    TRY(scream_attn_apply(qb, D, w.kv, b.tile_cloud, b.n_pairs, b.cloud_len, w.att, D, rs, st));
+    return mha_tail(L, w, x_src, y, rs, st);
+}
+
+}  // namespace
+
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi1"; }
+extern "C" int scream_abi_version(void) { return 1; }
+
+extern "C" int64_t scream_forward_workspace_bytes(int64_t rows_src, int64_t rows_total, int32_t n_pairs,
+                                                  int32_t max_chunks) {
+    if (rows_src < 0 || rows_total < rows_src || n_pairs < 0 || max_chunks < 0) return SCREAM_EINVAL;
+    return carve(nullptr, rows_total, n_pairs, max_chunks).bytes + 256;
+}
+
+extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t* batch, void* workspace,
+                              int64_t workspace_bytes, float* src_pred, float* feats_out, void* stream) {
+    SCREAM_REQUIRE(model && batch && workspace && src_pred, SCREAM_EINVAL);
+    const scream_model_t& m = *model;
+    const scream_batch_t& b = *batch;
+    SCREAM_REQUIRE(m.layers_host && m.n_self >= 0 && m.n_cross >= 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE(b.n_pairs > 0 && b.rows_src > 0 && b.rows_total > b.rows_src && b.max_chunks > 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE(b.rows_src % SCREAM_ROW_TILE == 0 && b.rows_total % SCREAM_ROW_TILE == 0, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE(b.xyz && b.center && b.tile_cloud && b.cloud_row0 && b.cloud_len, SCREAM_EINVAL);
+    uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
+    const Workspace w = carve(reinterpret_cast<void*>(base), b.rows_total, b.n_pairs, b.max_chunks);
+    SCREAM_REQUIRE((int64_t)(base - reinterpret_cast<uintptr_t>(workspace)) + w.bytes <= workspace_bytes, SCREAM_EINVAL);
+
+    const int64_t rs = b.rows_src, ra = b.rows_total;
+    TRY(scream_pe_embed_ln(b.xyz, b.tile_cloud, b.center, m.dim_t, m.emb_w, m.emb_b, m.pre_g, m.pre_b, w.x0, ra, stream));
+    float* cur = w.x0;
+    float* nxt = w.x1;
+    for (int i = 0; i < m.n_self; ++i) {  // pointnet.py:50-52
+        TRY(mha_self(m.layers_host[i], b, w, cur, nxt, ra, 2 * b.n_pairs, stream));
+        float* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    const float* x_tgt = cur + rs * D;  // frozen from here on: the cross stage only writes rows [0, rs)
+    for (int i = 0; i < 2 * m.n_cross; ++i) {  // pointnet.py:53-57
+        const scream_layer_t& L = m.layers_host[m.n_self + i];
+        if (i % 2 == 0) {
+            TRY(mha_self(L, b, w, cur, nxt, rs, b.n_pairs, stream));
+        } else {
+            TRY(mha_cross(L, b, w, cur, x_tgt, nxt, stream));
+        }
+        float* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    // coor_mlp, pointnet.py:27-33,60
+    TRY(scream_gemm_f32(cur, D, m.c0_w, w.m1, D, rs, D, D, SCREAM_EPI_BIAS_RELU, 0, m.c0_b, nullptr, 0, nullptr, nullptr, stream));
+    TRY(scream_gemm_f32(w.m1, D, m.c2_w, w.att, D, rs, D, D, SCREAM_EPI_BIAS_RELU, 0, m.c2_b, nullptr, 0, nullptr, nullptr, stream));
+    TRY(scream_coor_head(w.att, m.c4_w, m.c4_b, src_pred, rs, stream));
+    if (feats_out) {
+        hipError_t e = hipMemcpyAsync(feats_out, cur, (size_t)rs * D * sizeof(float), hipMemcpyDeviceToDevice,
+                                      as_stream(stream));
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}

@@ -1,0 +1,346 @@
+// A8 + A9 + A10: correspondence gather fused into the weighted Kabsch / Procrustes solve, and RE/TE.
+//
+// Reference: evaluate_3d_match.py:96-101 (gather), utils.py:138-178 (rigid_transform_3d; the reference
+// builds a dense K x K diag_embed and runs the 3x3 SVD on the HOST via H.cpu()), utils.py:181-189.
+// Here one workgroup owns one pair: two streaming passes over the correspondences (centroids, then
+// the 3x3 covariance H), sums carried in fp64 and reduced wave -> workgroup deterministically, then
+// the 3x3 SVD as a one-sided (Hestenes) Jacobi sweep held entirely in registers, evaluated redundantly by
+// every lane of wave 0 (the data is wave-uniform; no LDS, no divergence).  The rotation
+// R = V diag(1,1,det(V U^T)) U^T is invariant to the sign/order ambiguities of the SVD whenever the
+// reference's own result is well defined, so parity is checked on R|t, not on U, S, V.
+// Compiled with -ffp-contract=off: the fp32 steps (x / s + c, x - centroid, sum / (K + 1e-6)) are the
+// reference's individually rounded operations.
+#include "common.h"
+
+namespace {
+
+struct D3 {
+    double x, y, z;
+};
+
+__device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// Columns g[c][0..2] of G = H V and v[c][0..2] of V.  After convergence G's columns are orthogonal:
+// H = U S V^T with s_c = |g_c|, u_c = g_c / s_c.
+__device__ void jacobi_svd3(const double H[3][3], double U[3][3], double V[3][3], double sig[3]) {
+    double g[3][3], v[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            g[c][i] = H[i][c];
+            v[c][i] = (i == c) ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 16; ++sweep) {
+        double off = 0.0;
+#pragma unroll
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = (pq == 2) ? 1 : 0;
+            const int q = (pq == 0) ? 1 : 2;
+            const double alpha = dot3(g[p], g[p]), beta = dot3(g[q], g[q]), gamma = dot3(g[p], g[q]);
+            const double lim = 1e-30 + 1e-16 * sqrt(alpha * beta);
+            if (fabs(gamma) > lim) {
+                off += fabs(gamma);
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const double gp = g[p][i], gq = g[q][i];
+                    g[p][i] = cs * gp - sn * gq;
+                    g[q][i] = sn * gp + cs * gq;
+                    const double vp = v[p][i], vq = v[q][i];
+                    v[p][i] = cs * vp - sn * vq;
+                    v[q][i] = sn * vp + cs * vq;
+                }
+            }
+        }
+        if (off == 0.0) break;
+    }
+    double s[3] = {sqrt(dot3(g[0], g[0])), sqrt(dot3(g[1], g[1])), sqrt(dot3(g[2], g[2]))};
+    // sort columns by descending singular value (LAPACK order; the det fix applies to the smallest)
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        const int a = (pass == 1) ? 1 : 0, b = a + 1;
+        if (s[a] < s[b]) {
+            const double ts = s[a];
+            s[a] = s[b];
+            s[b] = ts;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double tg = g[a][i];
+                g[a][i] = g[b][i];
+                g[b][i] = tg;
+                tg = v[a][i];
+                v[a][i] = v[b][i];
+                v[b][i] = tg;
+            }
+        }
+    }
+    double u[3][3];
+    if (!(s[0] > 1e-300)) {
+        // H == 0 (no correspondences): torch.svd returns U = V = I -> identity transform (utils.py:155-175)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                u[c][i] = (i == c) ? 1.0 : 0.0;
+                v[c][i] = (i == c) ? 1.0 : 0.0;
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) u[0][i] = g[0][i] / s[0];
+        if (s[1] > 1e-14 * s[0]) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) u[1][i] = g[1][i] / s[1];
+        } else {
+            // rank 1: any unit vector orthogonal to u0 (rotation about u0 is undetermined in the reference too)
+            const int k = (fabs(u[0][0]) <= fabs(u[0][1]) && fabs(u[0][0]) <= fabs(u[0][2])) ? 0
+                          : (fabs(u[0][1]) <= fabs(u[0][2]) ? 1 : 2);
+            double e[3] = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0};
+            const double pr = dot3(e, u[0]);
+            double w[3] = {e[0] - pr * u[0][0], e[1] - pr * u[0][1], e[2] - pr * u[0][2]};
+            const double nw = sqrt(dot3(w, w));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) u[1][i] = w[i] / nw;
+        }
+        if (s[2] > 1e-14 * s[0]) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) u[2][i] = g[2][i] / s[2];
+        } else {  // rank <= 2: complete the basis; the sign cancels against det(V U^T) below
+            u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+            u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+            u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        sig[c] = s[c];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            U[i][c] = u[c][i];
+            V[i][c] = v[c][i];
+        }
+    }
+}
+
+__device__ __forceinline__ double det3(const double M[3][3]) {
+    return M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+           M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+}
+
+// R = V diag(1,1,det(V U^T)) U^T; t = cB - R cA (utils.py:169-175).  Writes a row-major 4x4.
+__device__ void solve_pose(const double H[3][3], const float cA[3], const float cB[3], float* T) {
+    double U[3][3], V[3][3], sig[3];
+    jacobi_svd3(H, U, V, sig);
+    const double delta = det3(V) * det3(U);  // det(V U^T)
+    float R[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            R[i][j] = (float)(V[i][0] * U[j][0] + V[i][1] * U[j][1] + delta * V[i][2] * U[j][2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double rc = (double)R[i][0] * cA[0] + (double)R[i][1] * cA[1] + (double)R[i][2] * cA[2];
+        T[i * 4 + 0] = R[i][0];
+        T[i * 4 + 1] = R[i][1];
+        T[i * 4 + 2] = R[i][2];
+        T[i * 4 + 3] = (float)((double)cB[i] - rc);
+    }
+    T[12] = 0.f;
+    T[13] = 0.f;
+    T[14] = 0.f;
+    T[15] = 1.f;
+}
+
+// Workgroup-wide sum of NV doubles per thread; result broadcast to every thread.  256 threads.
+template <int NV>
+__device__ void block_sum(double (&v)[NV], double* red /* [4][NV] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum_f64(v[k]);
+    __syncthreads();  // red may still be read from a previous call
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) red[wave * NV + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = (red[0 * NV + k] + red[1 * NV + k]) + (red[2 * NV + k] + red[3 * NV + k]);
+}
+
+struct CorrFetch {  // evaluate_3d_match.py:96-101
+    const float* src;
+    const float* ref;
+    const int32_t* idx;
+    const uint8_t* valid;
+    int64_t src_row0, ref_row0;
+    float s, c0, c1, c2;
+    int n;
+    __device__ __forceinline__ bool get(int i, float a[3], float b[3], float& w) const {
+        const int64_t row = src_row0 + i;
+        if (!valid[row]) return false;
+        const int64_t rrow = ref_row0 + (idx ? (int64_t)idx[row] : (int64_t)i);
+        a[0] = src[row * 3 + 0] / s + c0;
+        a[1] = src[row * 3 + 1] / s + c1;
+        a[2] = src[row * 3 + 2] / s + c2;
+        b[0] = ref[rrow * 3 + 0] / s + c0;
+        b[1] = ref[rrow * 3 + 1] / s + c1;
+        b[2] = ref[rrow * 3 + 2] / s + c2;
+        w = 1.0f;
+        return true;
+    }
+};
+
+struct DenseFetch {  // utils.py:138-151
+    const float* A;
+    const float* B;
+    const float* w;
+    float thr;
+    int n;
+    __device__ __forceinline__ bool get(int i, float a[3], float b[3], float& wt) const {
+        wt = w ? w[i] : 1.0f;
+        if (wt < thr) wt = 0.f;  // weights[weights < weight_threshold] = 0
+        if (wt == 0.f) return false;
+        a[0] = A[i * 3 + 0];
+        a[1] = A[i * 3 + 1];
+        a[2] = A[i * 3 + 2];
+        b[0] = B[i * 3 + 0];
+        b[1] = B[i * 3 + 1];
+        b[2] = B[i * 3 + 2];
+        return true;
+    }
+};
+
+template <class Fetch>
+__device__ void kabsch_block(const Fetch& f, float* T_out, int32_t* n_corr_out) {
+    __shared__ double red[4 * 9];
+    double acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    for (int i = threadIdx.x; i < f.n; i += 256) {
+        float a[3], b[3], w;
+        if (f.get(i, a, b, w)) {
+            acc[0] += (double)(a[0] * w);
+            acc[1] += (double)(a[1] * w);
+            acc[2] += (double)(a[2] * w);
+            acc[3] += (double)(b[0] * w);
+            acc[4] += (double)(b[1] * w);
+            acc[5] += (double)(b[2] * w);
+            acc[6] += (double)w;
+            acc[7] += 1.0;
+        }
+    }
+    block_sum<9>(acc, red);
+    const float denom = (float)acc[6] + 1e-6f;  // utils.py:155-158
+    const float cA[3] = {(float)acc[0] / denom, (float)acc[1] / denom, (float)acc[2] / denom};
+    const float cB[3] = {(float)acc[3] / denom, (float)acc[4] / denom, (float)acc[5] / denom};
+    const int count = (int)acc[7];
+
+    double h[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) h[k] = 0.0;
+    for (int i = threadIdx.x; i < f.n; i += 256) {
+        float a[3], b[3], w;
+        if (f.get(i, a, b, w)) {
+            const float am[3] = {a[0] - cA[0], a[1] - cA[1], a[2] - cA[2]};
+            const float bm[3] = {(b[0] - cB[0]) * w, (b[1] - cB[1]) * w, (b[2] - cB[2]) * w};
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) h[r * 3 + c] += (double)am[r] * (double)bm[c];
+        }
+    }
+    block_sum<9>(h, red);
+    if (threadIdx.x < 64) {  // wave 0, every lane redundantly (wave-uniform data)
+        double H[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) H[r][c] = (double)(float)h[r * 3 + c];  // the reference holds H in fp32
+        float T[16];
+        solve_pose(H, cA, cB, T);
+        if (threadIdx.x < 16) T_out[threadIdx.x] = T[threadIdx.x];
+        if (threadIdx.x == 0 && n_corr_out) *n_corr_out = count;
+    }
+}
+
+__global__ __launch_bounds__(256) void kabsch_corr_kernel(const float* __restrict__ src, const float* __restrict__ ref,
+                                                         const int32_t* __restrict__ src_row0,
+                                                         const int32_t* __restrict__ src_len,
+                                                         const int32_t* __restrict__ ref_row0,
+                                                         const int32_t* __restrict__ idx,
+                                                         const uint8_t* __restrict__ valid,
+                                                         const float* __restrict__ s, const float* __restrict__ c,
+                                                         float* __restrict__ T_out, int32_t* __restrict__ n_corr) {
+    const int p = blockIdx.x;
+    CorrFetch f{src, ref, idx, valid, src_row0[p], ref_row0[p], s[p], c[p * 3 + 0], c[p * 3 + 1], c[p * 3 + 2],
+                src_len[p]};
+    kabsch_block(f, T_out + p * 16, n_corr ? n_corr + p : nullptr);
+}
+
+__global__ __launch_bounds__(256) void kabsch_dense_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                          const float* __restrict__ w, float thr, int K,
+                                                          float* __restrict__ T_out) {
+    const int p = blockIdx.x;
+    DenseFetch f{A + (int64_t)p * K * 3, B + (int64_t)p * K * 3, w ? w + (int64_t)p * K : nullptr, thr, K};
+    kabsch_block(f, T_out + p * 16, nullptr);
+}
+
+// utils.py:181-189 with the fp32 operation order of torch-CPU (3-term fma chains for the 3x3 product).
+__global__ __launch_bounds__(64) void transformation_error_kernel(const float* __restrict__ Tp,
+                                                                 const float* __restrict__ Tg, int n,
+                                                                 float* __restrict__ re, float* __restrict__ te) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float* P = Tp + i * 16;
+    const float* G = Tg + i * 16;
+    float diag[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float d = P[0 * 4 + j] * G[0 * 4 + j];
+        d = __fmaf_rn(P[1 * 4 + j], G[1 * 4 + j], d);
+        d = __fmaf_rn(P[2 * 4 + j], G[2 * 4 + j], d);
+        diag[j] = d;
+    }
+    const float tr = (diag[0] + diag[1]) + diag[2];
+    float x = (tr - 1.0f) / 2.0f;
+    x = fminf(fmaxf(x, -1.0f), 1.0f);
+    re[i] = (acosf(x) * 180.0f) / 3.14159265358979323846f;
+    const float dx = P[3] - G[3], dy = P[7] - G[7], dz = P[11] - G[11];
+    te[i] = sqrtf((dx * dx + dy * dy) + dz * dz);
+}
+
+}  // namespace
+
+extern "C" int scream_kabsch_corr(const float* src, const float* ref, const int32_t* src_row0, const int32_t* src_len,
+                                  const int32_t* ref_row0, const int32_t* idx, const uint8_t* valid, const float* s,
+                                  const float* c, int32_t n_pairs, float* T_out, int32_t* n_corr, void* stream) {
+    SCREAM_REQUIRE(src && ref && src_row0 && src_len && ref_row0 && valid && s && c && T_out, SCREAM_EINVAL);
+    SCREAM_REQUIRE(n_pairs >= 0, SCREAM_EINVAL);
+    if (n_pairs == 0) return 0;
+    kabsch_corr_kernel<<<dim3(n_pairs), dim3(256), 0, as_stream(stream)>>>(src, ref, src_row0, src_len, ref_row0, idx,
+                                                                           valid, s, c, T_out, n_corr);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int scream_rigid_transform_3d(const float* A, const float* B, const float* w, float weight_threshold,
+                                         int32_t bs, int32_t K, float* T_out, void* stream) {
+    SCREAM_REQUIRE(T_out && bs >= 0 && K >= 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE(K == 0 || (A && B), SCREAM_EINVAL);
+    if (bs == 0) return 0;
+    kabsch_dense_kernel<<<dim3(bs), dim3(256), 0, as_stream(stream)>>>(A, B, w, weight_threshold, K, T_out);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int scream_transformation_error(const float* T_pred, const float* T_gt, int32_t n, float* re, float* te,
+                                           void* stream) {
+    SCREAM_REQUIRE(T_pred && T_gt && re && te && n >= 0, SCREAM_EINVAL);
+    if (n == 0) return 0;
+    transformation_error_kernel<<<dim3((n + 63) / 64), dim3(64), 0, as_stream(stream)>>>(T_pred, T_gt, n, re, te);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}

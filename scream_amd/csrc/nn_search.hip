@@ -1,0 +1,229 @@
+// A7: thresholded 1-nearest-neighbour search (evaluate_3d_match.py:94-95 / utils.py:72-78), brute force,
+// without the N x M distance matrix of the reference.
+//
+// Bit-exactness contract (see include/scream_hip.h): every operation below is an explicitly rounded
+// fp32 intrinsic in the order torch-CPU executes utils.py:75-77, so distances are bit-identical to
+// the reference and the arg-min (strict '<' while scanning targets in ascending order; 64-bit
+// (distance, index) keys when the target range is split over blocks) resolves ties to the lowest index.
+// This file is compiled with -ffp-contract=off as a second line of defence.
+//
+// Layout: targets are pre-divided once into float4 {bx, by, bz, |b|^2} (coalesced 16-byte reads);
+// a block stages 1024 targets (16 KiB) in LDS and every lane scans them with wave-uniform
+// (broadcast) ds_read_b128; each thread carries QPT query points, so one LDS read feeds QPT x 8 VALU
+// ops.  The kernel is VALU-bound (8 flop per pair over 12 bytes per POINT), not HBM-bound.
+#include "common.h"
+
+namespace {
+
+constexpr int QPT = 4;              // queries per thread
+constexpr int QB = 256 * QPT;       // queries per block
+constexpr int RT = 1024;            // targets per LDS tile
+
+__device__ __forceinline__ uint32_t f32_orderable(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_orderable(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// grid (ceil(max_r_len/256), n_pairs): ref_prep[row] = {b/s, |b/s|^2}
+__global__ __launch_bounds__(256) void nn_prep_kernel(const float* __restrict__ ref, const int32_t* __restrict__ r_row0,
+                                                     const int32_t* __restrict__ r_len, const float* __restrict__ s,
+                                                     float* __restrict__ ref_prep) {
+    const int p = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= r_len[p]) return;
+    const int64_t row = (int64_t)r_row0[p] + i;
+    const float sp = s[p];
+    const float bx = __fdiv_rn(ref[row * 3 + 0], sp);
+    const float by = __fdiv_rn(ref[row * 3 + 1], sp);
+    const float bz = __fdiv_rn(ref[row * 3 + 2], sp);
+    const float sb = __fadd_rn(__fadd_rn(__fmul_rn(bx, bx), __fmul_rn(by, by)), __fmul_rn(bz, bz));
+    f32x4 o = {bx, by, bz, sb};
+    *reinterpret_cast<f32x4*>(ref_prep + row * 4) = o;
+}
+
+__global__ __launch_bounds__(256) void nn_init_keys_kernel(uint64_t* __restrict__ keys, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = ~0ull;
+}
+
+// grid (ceil(max_q_len/QB), r_splits, n_pairs)
+__global__ __launch_bounds__(256) void nn_search_kernel(const float* __restrict__ query,
+                                                       const float* __restrict__ ref_prep,
+                                                       const int32_t* __restrict__ q_row0,
+                                                       const int32_t* __restrict__ q_len,
+                                                       const int32_t* __restrict__ r_row0,
+                                                       const int32_t* __restrict__ r_len,
+                                                       const float* __restrict__ s, int r_per_split,
+                                                       uint64_t* __restrict__ keys) {
+    __shared__ __attribute__((aligned(16))) float tile[RT * 4];
+    const int p = blockIdx.z;
+    const int nq = q_len[p], nr = r_len[p];
+    const int qb0 = blockIdx.x * QB;
+    const int j_begin = blockIdx.y * r_per_split;
+    const int j_end = min(nr, j_begin + r_per_split);
+    if (qb0 >= nq || j_begin >= j_end) return;  // block-uniform
+    const int tid = threadIdx.x;
+    const float sp = s[p];
+    const int64_t qrow0 = q_row0[p];
+    const float* rp = ref_prep + (int64_t)r_row0[p] * 4;
+
+    float ax[QPT], ay[QPT], az[QPT], sa[QPT], best[QPT];
+    int bi[QPT];
+#pragma unroll
+    for (int u = 0; u < QPT; ++u) {
+        const int qi = qb0 + tid + 256 * u;
+        const int64_t row = qrow0 + min(qi, nq - 1);  // clamp: out-of-range slots recompute the last point, never stored
+        ax[u] = __fdiv_rn(query[row * 3 + 0], sp);
+        ay[u] = __fdiv_rn(query[row * 3 + 1], sp);
+        az[u] = __fdiv_rn(query[row * 3 + 2], sp);
+        sa[u] = __fadd_rn(__fadd_rn(__fmul_rn(ax[u], ax[u]), __fmul_rn(ay[u], ay[u])), __fmul_rn(az[u], az[u]));
+        best[u] = __builtin_inff();
+        bi[u] = 0x7fffffff;
+    }
+
+    for (int jt = j_begin; jt < j_end; jt += RT) {
+        const int cnt = min(RT, j_end - jt);
+        __syncthreads();
+        for (int i = tid; i < cnt; i += 256)
+            *reinterpret_cast<f32x4*>(tile + i * 4) = *reinterpret_cast<const f32x4*>(rp + (int64_t)(jt + i) * 4);
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < cnt; ++j) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(tile + j * 4);  // wave-uniform address: broadcast
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) {
+                float dot = __fmul_rn(ax[u], b[0]);
+                dot = __fmaf_rn(ay[u], b[1], dot);
+                dot = __fmaf_rn(az[u], b[2], dot);
+                // -2*dot is exact, so fma(-2, dot, |a|^2) rounds exactly like (-2*dot) + |a|^2
+                const float d = __fadd_rn(__fmaf_rn(-2.0f, dot, sa[u]), b[3]);
+                if (d < best[u]) {
+                    best[u] = d;
+                    bi[u] = jt + j;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < QPT; ++u) {
+        const int qi = qb0 + tid + 256 * u;
+        if (qi < nq && bi[u] != 0x7fffffff) {
+            const uint64_t key = ((uint64_t)f32_orderable(best[u]) << 32) | (uint32_t)bi[u];
+            atomicMin(reinterpret_cast<unsigned long long*>(keys + qrow0 + qi), (unsigned long long)key);
+        }
+    }
+}
+
+// grid (ceil(max_q_len/256), n_pairs)
+__global__ __launch_bounds__(256) void nn_finalize_kernel(const uint64_t* __restrict__ keys,
+                                                         const int32_t* __restrict__ q_row0,
+                                                         const int32_t* __restrict__ q_len, float thresh,
+                                                         int32_t* __restrict__ idx, float* __restrict__ dmin,
+                                                         uint8_t* __restrict__ valid) {
+    const int p = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= q_len[p]) return;
+    const int64_t row = (int64_t)q_row0[p] + i;
+    const uint64_t key = keys[row];
+    if (key == ~0ull) {  // empty target cloud
+        idx[row] = -1;
+        dmin[row] = __builtin_inff();
+        valid[row] = 0;
+        return;
+    }
+    const float d = f32_from_orderable((uint32_t)(key >> 32));
+    idx[row] = (int32_t)(uint32_t)key;
+    dmin[row] = d;
+    valid[row] = d < thresh ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void nn_fill_padding_kernel(int32_t* __restrict__ idx, float* __restrict__ dmin,
+                                                             uint8_t* __restrict__ valid, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        idx[i] = -1;
+        dmin[i] = __builtin_inff();
+        valid[i] = 0;
+    }
+}
+
+// Dense utils.square_distance (utils.py:72-78) for API compatibility only: the hot path never
+// materialises N x M.  grid (ceil(M/256), min(N,65535), B); same rounding sequence as nn_search_kernel.
+__global__ __launch_bounds__(256) void square_distance_kernel(const float* __restrict__ src,
+                                                             const float* __restrict__ dst, float* __restrict__ out,
+                                                             int N, int M) {
+    const int b = blockIdx.z;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float* bp = dst + ((int64_t)b * M + m) * 3;
+    const float bx = bp[0], by = bp[1], bz = bp[2];
+    const float sb = __fadd_rn(__fadd_rn(__fmul_rn(bx, bx), __fmul_rn(by, by)), __fmul_rn(bz, bz));
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        const float* ap = src + ((int64_t)b * N + n) * 3;
+        const float ax = ap[0], ay = ap[1], az = ap[2];
+        const float sa = __fadd_rn(__fadd_rn(__fmul_rn(ax, ax), __fmul_rn(ay, ay)), __fmul_rn(az, az));
+        float dot = __fmul_rn(ax, bx);
+        dot = __fmaf_rn(ay, by, dot);
+        dot = __fmaf_rn(az, bz, dot);
+        out[((int64_t)b * N + n) * M + m] = __fadd_rn(__fmaf_rn(-2.0f, dot, sa), sb);
+    }
+}
+
+}  // namespace
+
+extern "C" int scream_square_distance(const float* src, const float* dst, float* out, int32_t B, int32_t N, int32_t M,
+                                      void* stream) {
+    SCREAM_REQUIRE(B >= 0 && N >= 0 && M >= 0, SCREAM_EINVAL);
+    if (B == 0 || N == 0 || M == 0) return 0;
+    SCREAM_REQUIRE(src && dst && out, SCREAM_EINVAL);
+    SCREAM_REQUIRE(B <= 65535, SCREAM_EUNSUPPORTED);
+    square_distance_kernel<<<dim3((M + 255) / 256, N < 65535 ? N : 65535, B), dim3(256), 0, as_stream(stream)>>>(
+        src, dst, out, N, M);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int scream_nn_search(const float* query, const float* ref, const int32_t* q_row0, const int32_t* q_len,
+                                const int32_t* r_row0, const int32_t* r_len, const float* s, int32_t n_pairs,
+                                int32_t max_q_len, int32_t max_r_len, int64_t q_rows_total, int64_t r_rows_total,
+                                float thresh, float* ref_prep, uint64_t* keys, int32_t* idx, float* dmin,
+                                uint8_t* valid, void* stream) {
+    SCREAM_REQUIRE(query && ref && q_row0 && q_len && r_row0 && r_len && s && ref_prep && keys && idx && dmin && valid,
+                   SCREAM_EINVAL);
+    SCREAM_REQUIRE(n_pairs >= 0 && max_q_len >= 0 && max_r_len >= 0 && q_rows_total >= 0 && r_rows_total >= 0,
+                   SCREAM_EINVAL);
+    SCREAM_REQUIRE(n_pairs <= 65535, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(ref_prep) & 15) == 0, SCREAM_EINVAL);
+    if (n_pairs == 0 || q_rows_total == 0) return 0;
+    hipStream_t st = as_stream(stream);
+    const unsigned qblk = (unsigned)((q_rows_total + 255) / 256);
+    nn_init_keys_kernel<<<dim3(qblk), dim3(256), 0, st>>>(keys, q_rows_total);
+    SCREAM_LAUNCH_CHECK();
+    nn_fill_padding_kernel<<<dim3(qblk), dim3(256), 0, st>>>(idx, dmin, valid, q_rows_total);
+    SCREAM_LAUNCH_CHECK();
+    if (max_q_len == 0) return 0;
+    if (max_r_len > 0) {
+        nn_prep_kernel<<<dim3((max_r_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(ref, r_row0, r_len, s, ref_prep);
+        SCREAM_LAUNCH_CHECK();
+        const int qblocks = (max_q_len + QB - 1) / QB;
+        // split the target range until the grid has >= ~4 blocks per CU; every split is a whole number of LDS tiles
+        int splits = (1024 + qblocks * n_pairs - 1) / (qblocks * n_pairs);
+        const int max_splits = (max_r_len + RT - 1) / RT;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        if (splits > 65535) splits = 65535;
+        int r_per_split = (max_r_len + splits - 1) / splits;
+        r_per_split = (r_per_split + RT - 1) / RT * RT;
+        splits = (max_r_len + r_per_split - 1) / r_per_split;
+        nn_search_kernel<<<dim3(qblocks, splits, n_pairs), dim3(256), 0, st>>>(query, ref_prep, q_row0, q_len, r_row0,
+                                                                              r_len, s, r_per_split, keys);
+        SCREAM_LAUNCH_CHECK();
+    }
+    nn_finalize_kernel<<<dim3((max_q_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(keys, q_row0, q_len, thresh, idx,
+                                                                                     dmin, valid);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}

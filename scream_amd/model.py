@@ -1,0 +1,180 @@
+"""PointTransformer: the reference's model surface (models/pointnet.py:8-99) on the HIP kernels.
+
+The module tree exists to hold parameters under the reference's 190 state_dict names, so
+``load_state_dict(torch.load("params/point-generator.pth"))`` works unchanged.  No submodule's
+``forward`` is ever used: ``PointTransformer.forward`` packs the pair(s) and makes one
+``scream_forward`` C-ABI call (scream_amd/csrc/forward.hip).  Running it on anything but an
+MI355X raises: there is no CPU path in the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+from .packing import PackedBatch
+
+D_MODEL = 256
+NHEAD = 8
+
+
+class _MHAParams(nn.Module):
+    """Parameter holder with the names of models/transformer.py:47-72."""
+
+    def __init__(self, d_model: int, nhead: int = NHEAD):
+        super().__init__()
+        self.q_proj = nn.Linear(d_model, d_model, bias=False)
+        self.k_proj = nn.Linear(d_model, d_model, bias=False)
+        self.v_proj = nn.Linear(d_model, d_model, bias=False)
+        self.merge = nn.Linear(d_model, d_model, bias=False)
+        self.mlp = nn.Sequential(nn.Linear(d_model, d_model * 4, bias=False), nn.ReLU(True),
+                                 nn.Linear(d_model * 4, d_model, bias=False))
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+
+class _CrossParams(nn.Module):
+    """models/transformer.py:110-121: the MHAttention lives under ``.layer`` and is xavier-initialised."""
+
+    def __init__(self, d_model: int, nhead: int = NHEAD):
+        super().__init__()
+        self.layer = _MHAParams(d_model, nhead)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+
+def pe_dim_t(d_model: int = D_MODEL) -> torch.Tensor:
+    """Frequency table of the sine embedding, computed with the same torch-CPU ops as
+    models/transformer.py:168-170 so the table is bit-identical to the reference's."""
+    npf = d_model // 3 // 2 * 2
+    i = torch.arange(npf, dtype=torch.float32)
+    return 10000 ** (2 * torch.trunc(torch.div(i, 2)) / npf)
+
+
+class PointTransformer(nn.Module):
+    def __init__(self, d_model: int = 256, self_layer_num: int = 6, cross_layer_num: int = 6):
+        super().__init__()
+        if d_model != D_MODEL:
+            raise NotImplementedError("the gfx950 kernels are built for d_model=256 (8 heads x 32), the only "
+                                      "configuration the reference evaluates (evaluate_3d_match.py:188)")
+        self.embedding = nn.Conv1d(3, d_model, kernel_size=1, stride=1)
+        self.pre_norm = nn.LayerNorm(d_model)
+        self.self_layer_num = self_layer_num
+        self.cross_layer_num = cross_layer_num
+        self.stem = nn.ModuleList([_MHAParams(d_model) for _ in range(self_layer_num)])
+        self.cross = nn.ModuleList()
+        for _ in range(cross_layer_num):
+            self.cross.append(_MHAParams(d_model))
+            self.cross.append(_CrossParams(d_model))
+        self.coor_mlp = nn.Sequential(nn.Conv1d(d_model, d_model, 1), nn.ReLU(), nn.Conv1d(d_model, d_model, 1),
+                                      nn.ReLU(), nn.Conv1d(d_model, 3, 1))
+        # models/pointnet.py:36 builds a RegistrationRender here; it owns no parameters or buffers and is
+        # only used when get_imgs=True (training-time GAN loss) -- out of scope, see DESIGN.md.
+        self._packed = None
+        self._packed_sig = None
+        self._ws = None
+
+    # ------------------------------------------------------------------ weights -> kernel layout
+    def _layer_modules(self) -> List[_MHAParams]:
+        mods = list(self.stem)
+        for i, m in enumerate(self.cross):
+            mods.append(m if i % 2 == 0 else m.layer)
+        return mods
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _pack_weights(self):
+        sig = self._signature()
+        if self._packed is not None and sig == self._packed_sig:
+            return self._packed
+        dev = self.embedding.weight.device
+        if dev.type != "cuda":
+            raise _lib.ScreamHipError("PointTransformer must be on the MI355X (net.to('cuda:0')) before forward; "
+                                      "scream_amd has no CPU path")
+        keep = []  # device tensors the ctypes structs point into
+
+        def dev_f32(t):
+            t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        mods = self._layer_modules()
+        layers = (_lib.LayerT * len(mods))()
+        for L, m in zip(layers, mods):
+            L.wqkv = dev_f32(torch.cat([m.q_proj.weight, m.k_proj.weight, m.v_proj.weight], dim=0))
+            L.wm = dev_f32(m.merge.weight)
+            L.w1 = dev_f32(m.mlp[0].weight)
+            L.w2 = dev_f32(m.mlp[2].weight)
+            L.g1, L.b1 = dev_f32(m.norm1.weight), dev_f32(m.norm1.bias)
+            L.g2, L.b2 = dev_f32(m.norm2.weight), dev_f32(m.norm2.bias)
+        mt = _lib.ModelT()
+        mt.n_self, mt.n_cross = self.self_layer_num, self.cross_layer_num
+        mt.dim_t = dev_f32(pe_dim_t())
+        mt.emb_w = dev_f32(self.embedding.weight[:, :, 0])
+        mt.emb_b = dev_f32(self.embedding.bias)
+        mt.pre_g, mt.pre_b = dev_f32(self.pre_norm.weight), dev_f32(self.pre_norm.bias)
+        mt.layers_host = C.cast(layers, C.POINTER(_lib.LayerT))
+        mt.c0_w, mt.c0_b = dev_f32(self.coor_mlp[0].weight[:, :, 0]), dev_f32(self.coor_mlp[0].bias)
+        mt.c2_w, mt.c2_b = dev_f32(self.coor_mlp[2].weight[:, :, 0]), dev_f32(self.coor_mlp[2].bias)
+        mt.c4_w, mt.c4_b = dev_f32(self.coor_mlp[4].weight[:, :, 0]), dev_f32(self.coor_mlp[4].bias)
+        self._packed = (mt, layers, keep)
+        self._packed_sig = sig
+        return self._packed
+
+    # ------------------------------------------------------------------ batched entry
+    def forward_packed(self, batch: PackedBatch, return_feats: bool = False):
+        """A1-A6 for every pair of the batch in one C-ABI call; returns src_pred packed [rows_src, 3]."""
+        mt, _layers, _keep = self._pack_weights()
+        lib = _lib.load()
+        dev = batch.xyz.device
+        need = lib.scream_forward_workspace_bytes(batch.rows_src, batch.rows_total, batch.n_pairs, batch.max_chunks)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        bt = _lib.BatchT()
+        bt.n_pairs, bt.rows_src, bt.rows_total, bt.max_chunks = batch.n_pairs, batch.rows_src, batch.rows_total, batch.max_chunks
+        bt.xyz, bt.center = ops._p(batch.xyz), ops._p(batch.center)
+        bt.tile_cloud = ops._p(batch.tile_cloud, torch.int32)
+        bt.cloud_row0 = ops._p(batch.cloud_row0, torch.int32)
+        bt.cloud_len = ops._p(batch.cloud_len, torch.int32)
+        src_pred = torch.empty(batch.rows_src, 3, device=dev, dtype=torch.float32)
+        feats = torch.empty(batch.rows_src, D_MODEL, device=dev, dtype=torch.float32) if return_feats else None
+        _lib.check(lib.scream_forward(C.byref(mt), C.byref(bt), self._ws.data_ptr(), self._ws.numel(),
+                                      src_pred.data_ptr(), feats.data_ptr() if return_feats else None,
+                                      ops._stream()), "scream_forward")
+        return (src_pred, feats) if return_feats else src_pred
+
+    def forward_batch(self, srcs: Sequence[torch.Tensor], tgts: Sequence[torch.Tensor],
+                      centers: Optional[Sequence[Optional[torch.Tensor]]] = None) -> List[torch.Tensor]:
+        """B pairs at once: srcs[i] [N_i,3], tgts[i] [M_i,3]; returns [src_pred_i [N_i,3]] -- each equal to
+        what the B == 1 reference forward gives for that pair."""
+        batch = PackedBatch.from_pairs(srcs, tgts, centers)
+        return [t.clone() for t in batch.unpack_src(self.forward_packed(batch))]
+
+    # ------------------------------------------------------------------ the reference's signature
+    @torch.no_grad()
+    def forward(self, src, tgt, src_center=None, s=1, get_imgs=False, get_transform=False, filter=None):
+        """models/pointnet.py:38-91.  Inference only (the reference wraps evaluation in no_grad)."""
+        assert src.shape[0] == 1, "batch size must 1"
+        assert tgt.shape[0] == 1, "batch size must 1"
+        if get_imgs:
+            raise NotImplementedError("get_imgs=True (depth renderer for the training-time GAN loss, "
+                                      "models/render.py) is out of scope; every evaluate_* call passes False")
+        center = None if src_center is None else src_center.reshape(3)
+        batch = PackedBatch.from_pairs([src[0]], [tgt[0]], [center])
+        src_ = self.forward_packed(batch)[: src.shape[1]].unsqueeze(0).clone()
+        transform = None
+        if get_transform:  # pointnet.py:66-74: NN against `filter` at 0.075, Kabsch in the normalised frame
+            from .geometry import register_from_prediction
+            ref = tgt[0] if filter is None else filter[0]
+            transform = register_from_prediction(src[0], src_[0], ref, float(s), 0.075)
+        return src_, None, transform
+
+    def loss(self, src_pred, src_pcd, rot_gt, trans_gt):
+        """models/pointnet.py:93-99 (L1 point loss; metric bookkeeping, not a hot-path kernel)."""
+        reg = (torch.matmul(rot_gt, src_pcd.permute([0, 2, 1])) + trans_gt).permute([0, 2, 1])
+        return torch.mean(torch.sum(torch.abs(src_pred - reg), dim=-1), dim=1).mean(dim=0)

@@ -1,0 +1,139 @@
+"""Thin host wrappers: torch device tensors in, one C-ABI call (include/scream_hip.h) each.
+
+torch is plumbing here (device memory + the current HIP stream); all arithmetic happens in
+libscream_hip.so.  There is no CPU fallback: a tensor that is not on a HIP device is an error.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+EPI_NONE, EPI_ELU1, EPI_RELU, EPI_BIAS_RELU, EPI_RES_LN = 0, 1, 2, 3, 4
+ROW_TILE = 128
+KV_CHUNK = 256
+KV_ELEMS = 33 * 32
+D_MODEL = 256
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.ScreamHipError("scream_amd ops need tensors on the MI355X (got device %s); there is no CPU path" % t.device)
+    if t.dtype != dtype:
+        raise TypeError("expected %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def gemm_f32(A: torch.Tensor, W: torch.Tensor, epilogue: int = EPI_NONE, n_act: int = 0,
+             bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+             gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = epilogue(A @ W.T); A [M,K] (M % 128 == 0), W [N,K] (N % 256 == 0, K % 32 == 0)."""
+    M, K = A.shape
+    N = W.shape[0]
+    assert W.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    lib = _lib.load()
+    check(lib.scream_gemm_f32(_p(A), A.stride(0), _p(W), _p(out), out.stride(0), M, N, K, epilogue, n_act,
+                              _p(bias), _p(residual), residual.stride(0) if residual is not None else 0,
+                              _p(gamma), _p(beta), _stream()), "scream_gemm_f32")
+    return out
+
+
+def pe_embed_ln(xyz, tile_cloud, center, dim_t, emb_w, emb_b, gamma, beta) -> torch.Tensor:
+    rows = xyz.shape[0]
+    feats = torch.empty(rows, D_MODEL, device=xyz.device, dtype=torch.float32)
+    check(_lib.load().scream_pe_embed_ln(_p(xyz), _p(tile_cloud, torch.int32), _p(center), _p(dim_t), _p(emb_w),
+                                         _p(emb_b), _p(gamma), _p(beta), _p(feats), rows, _stream()),
+          "scream_pe_embed_ln")
+    return feats
+
+
+def kv_reduce(Kf: torch.Tensor, Vf: torch.Tensor, ld: int, row_base: int, cloud_row0, cloud_len, cloud_begin: int,
+              n_kv: int, max_chunks: int, n_clouds: int) -> torch.Tensor:
+    """Kf / Vf: views whose data_ptr is column 0 of the keys / values (row stride ld floats)."""
+    dev = Kf.device
+    partial = torch.empty(max(n_kv * max_chunks * 8 * KV_ELEMS, 1), device=dev, dtype=torch.float32)
+    kv = torch.zeros(n_clouds, 8, KV_ELEMS, device=dev, dtype=torch.float32)
+    for t in (Kf, Vf):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise TypeError("kv_reduce needs fp32 device tensors")
+    check(_lib.load().scream_kv_reduce(Kf.data_ptr(), Vf.data_ptr(), ld, row_base, _p(cloud_row0, torch.int32),
+                                       _p(cloud_len, torch.int32), cloud_begin, n_kv, max_chunks, _p(partial),
+                                       _p(kv), _stream()), "scream_kv_reduce")
+    return kv
+
+
+def attn_apply(Qf: torch.Tensor, ldq: int, kv, tile_cloud, kv_cloud_offset: int, cloud_len, rows: int) -> torch.Tensor:
+    out = torch.empty(rows, D_MODEL, device=kv.device, dtype=torch.float32)
+    check(_lib.load().scream_attn_apply(Qf.data_ptr(), ldq, _p(kv), _p(tile_cloud, torch.int32), kv_cloud_offset,
+                                        _p(cloud_len, torch.int32), _p(out), D_MODEL, rows, _stream()),
+          "scream_attn_apply")
+    return out
+
+
+def coor_head(X: torch.Tensor, W: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    rows = X.shape[0]
+    out = torch.empty(rows, 3, device=X.device, dtype=torch.float32)
+    check(_lib.load().scream_coor_head(_p(X), _p(W), _p(b), _p(out), rows, _stream()), "scream_coor_head")
+    return out
+
+
+def nn_search(query: torch.Tensor, ref: torch.Tensor, q_row0, q_len, r_row0, r_len, s: torch.Tensor,
+              max_q_len: int, max_r_len: int, thresh: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Packed thresholded 1-NN.  Returns (idx int32, dmin fp32, valid uint8), one entry per packed query row."""
+    dev = query.device
+    qn, rn = query.shape[0], ref.shape[0]
+    n_pairs = s.shape[0]
+    ref_prep = torch.empty(max(rn, 1), 4, device=dev, dtype=torch.float32)
+    keys = torch.empty(max(qn, 1), device=dev, dtype=torch.int64)
+    idx = torch.empty(qn, device=dev, dtype=torch.int32)
+    dmin = torch.empty(qn, device=dev, dtype=torch.float32)
+    valid = torch.empty(qn, device=dev, dtype=torch.uint8)
+    check(_lib.load().scream_nn_search(_p(query), _p(ref), _p(q_row0, torch.int32), _p(q_len, torch.int32),
+                                       _p(r_row0, torch.int32), _p(r_len, torch.int32), _p(s), n_pairs, max_q_len,
+                                       max_r_len, qn, rn, float(thresh), _p(ref_prep), _p(keys, torch.int64),
+                                       _p(idx, torch.int32), _p(dmin), _p(valid, torch.uint8), _stream()),
+          "scream_nn_search")
+    return idx, dmin, valid
+
+
+def kabsch_corr(src, ref, src_row0, src_len, ref_row0, idx, valid, s, c) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Returns (T [n_pairs,4,4], n_corr int32 [n_pairs])."""
+    n_pairs = s.shape[0]
+    T = torch.empty(n_pairs, 4, 4, device=src.device, dtype=torch.float32)
+    n_corr = torch.empty(n_pairs, device=src.device, dtype=torch.int32)
+    check(_lib.load().scream_kabsch_corr(_p(src), _p(ref), _p(src_row0, torch.int32), _p(src_len, torch.int32),
+                                         _p(ref_row0, torch.int32), _p(idx, torch.int32), _p(valid, torch.uint8),
+                                         _p(s), _p(c), n_pairs, _p(T), _p(n_corr, torch.int32), _stream()),
+          "scream_kabsch_corr")
+    return T, n_corr
+
+
+def rigid_transform_3d_dense(A: torch.Tensor, B: torch.Tensor, w: Optional[torch.Tensor], thr: float) -> torch.Tensor:
+    bs, K = A.shape[0], A.shape[1]
+    T = torch.empty(bs, 4, 4, device=A.device, dtype=torch.float32)
+    check(_lib.load().scream_rigid_transform_3d(_p(A) if K else None, _p(B) if K else None, _p(w), float(thr), bs, K,
+                                                _p(T), _stream()), "scream_rigid_transform_3d")
+    return T
+
+
+def transformation_error_batched(T_pred: torch.Tensor, T_gt: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    n = T_pred.shape[0]
+    re = torch.empty(n, device=T_pred.device, dtype=torch.float32)
+    te = torch.empty(n, device=T_pred.device, dtype=torch.float32)
+    check(_lib.load().scream_transformation_error(_p(T_pred), _p(T_gt), n, _p(re), _p(te), _stream()),
+          "scream_transformation_error")
+    return re, te

@@ -92,9 +92,9 @@ def voxel_downsample(pts: np.ndarray, voxel: float) -> np.ndarray:
 
 
 def _room_points(rng: np.random.Generator, n_samples: int) -> np.ndarray:
-    """Three box faces meeting at a corner of a 3.0 x 2.5 x 2.5 m room + two interior planar patches."""
+    """Three box faces meeting at a corner of a 3.0 x 2.5 x 2.5 m room + two interior 1.5 x 1.6 m planar patches."""
     lx, ly, lz = 3.0, 2.5, 2.5
-    areas = np.array([lx * ly, lx * lz, ly * lz, 1.0, 1.0])
+    areas = np.array([lx * ly, lx * lz, ly * lz, 2.4, 2.4])
     counts = np.maximum((areas / areas.sum() * n_samples).astype(int), 1)
     parts = []
     u = rng.uniform(size=(counts[0], 2)); parts.append(np.stack([u[:, 0] * lx, u[:, 1] * ly, np.zeros(counts[0])], 1))
@@ -104,8 +104,8 @@ def _room_points(rng: np.random.Generator, n_samples: int) -> np.ndarray:
         origin = rng.uniform([0.5, 0.5, 0.3], [lx - 1.0, ly - 1.0, lz - 1.0])
         Rp = random_rotation(rng, 60.0)
         u = rng.uniform(size=(counts[k], 2))
-        parts.append(origin + (np.stack([u[:, 0], u[:, 1], np.zeros(counts[k])], 1) @ Rp.T))
-    pts = np.concatenate(parts, 0)
+        parts.append(origin + (np.stack([1.5 * u[:, 0], 1.6 * u[:, 1], np.zeros(counts[k])], 1) @ Rp.T))
+    pts = np.concatenate(parts, 0) + 0.03125  # walls sit mid-voxel, as a scanned wall rarely straddles two cells
     return pts + rng.normal(scale=0.005, size=pts.shape)
 
 

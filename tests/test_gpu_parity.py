@@ -1,0 +1,309 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference-generated
+golden vectors.  Needs an MI355X: run with `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scream_ref as O
+from scream_amd import ops
+from scream_amd.synthetic import make_3dmatch_pair, make_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu_and_native_lib():
+    assert torch.cuda.is_available(), "pytest -m gpu needs the MI355X"
+    from scream_amd import _lib
+    _lib.load()  # fails loudly if libscream_hip.so is missing: there is no fallback path to test
+
+
+def dev(x):
+    return torch.as_tensor(x).to(DEV)
+
+
+def build_net(seed, n_self, n_cross):
+    from scream_amd.model import PointTransformer
+    net = PointTransformer(256, n_self, n_cross)
+    net.load_state_dict(make_state_dict(seed, 256, n_self, n_cross), strict=True)
+    return net.to(DEV).eval()
+
+
+# ------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 256, 256), (384, 768, 256), (256, 1024, 256), (256, 256, 1024), (128, 512, 32)])
+def test_gemm_plain_and_activations(M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    ref = (A.double() @ W.double().t())
+    out = ops.gemm_f32(dev(A), dev(W)).cpu()
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=2e-5)
+    out = ops.gemm_f32(dev(A), dev(W), ops.EPI_RELU).cpu()
+    torch.testing.assert_close(out.double(), ref.clamp_min(0), rtol=1e-5, atol=2e-5)
+    if N >= 512:
+        out = ops.gemm_f32(dev(A), dev(W), ops.EPI_ELU1, n_act=N - 256).cpu()
+        want = ref.clone()
+        want[:, : N - 256] = torch.nn.functional.elu(ref[:, : N - 256]) + 1
+        torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=2e-5)
+    bias = torch.randn(N, generator=g)
+    out = ops.gemm_f32(dev(A), dev(W), ops.EPI_BIAS_RELU, bias=dev(bias)).cpu()
+    torch.testing.assert_close(out.double(), (ref + bias.double()).clamp_min(0), rtol=1e-5, atol=2e-5)
+
+
+def test_gemm_asymmetric_identity():
+    """A = I with an asymmetric W catches a transposed fragment/C map (cdna guide, section 3)."""
+    K = N = 256
+    A = torch.zeros(128, K)
+    A[torch.arange(128), torch.arange(128)] = 1.0
+    W = torch.arange(N * K, dtype=torch.float32).reshape(N, K) / 1000.0
+    out = ops.gemm_f32(dev(A), dev(W)).cpu()
+    torch.testing.assert_close(out, W.t()[:128].contiguous(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("K", [256, 1024])
+def test_gemm_residual_layernorm(K):
+    g = torch.Generator().manual_seed(K)
+    M, N = 256, 256
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    res = torch.randn(M, N, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    want = torch.nn.functional.layer_norm((A.double() @ W.double().t()) + res.double(), (N,), gamma.double(), beta.double(), 1e-5)
+    out = ops.gemm_f32(dev(A), dev(W), ops.EPI_RES_LN, residual=dev(res), gamma=dev(gamma), beta=dev(beta)).cpu()
+    torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=2e-5)
+
+
+def test_gemm_rejects_bad_shapes():
+    from scream_amd._lib import ScreamHipError
+    with pytest.raises(ScreamHipError):
+        ops.gemm_f32(dev(torch.zeros(100, 256)), dev(torch.zeros(256, 256)))
+    with pytest.raises(ScreamHipError):
+        ops.gemm_f32(torch.zeros(128, 256), torch.zeros(256, 256))  # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------ A1 embedding
+def test_pe_embed_prenorm_vs_oracle(golden):
+    from scream_amd.model import pe_dim_t
+    from scream_amd.packing import PackedBatch
+    sd = make_state_dict(3, 256, 1, 1)
+    rng = np.random.default_rng(0)
+    src = torch.from_numpy(rng.uniform(-1, 1, size=(150, 3)).astype(np.float32))
+    tgt = torch.from_numpy(rng.uniform(-1, 1, size=(70, 3)).astype(np.float32))
+    center = torch.tensor([0.1, -0.2, 0.05])
+    b = PackedBatch.from_pairs([dev(src)], [dev(tgt)], [dev(center)])
+    feats = ops.pe_embed_ln(b.xyz, b.tile_cloud, b.center, dev(pe_dim_t()), dev(sd["embedding.weight"][:, :, 0].contiguous()),
+                            dev(sd["embedding.bias"]), dev(sd["pre_norm.weight"]), dev(sd["pre_norm.bias"])).cpu()
+    want_s = O.embed_prenorm(src, src - center, sd)
+    want_t = O.embed_prenorm(tgt, tgt, sd)
+    torch.testing.assert_close(feats[:150], want_s, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(feats[b.rows_src: b.rows_src + 70], want_t, rtol=1e-4, atol=2e-5)
+
+
+# ---------------------------------------------------------------------- A3 linear attention
+def test_linear_attention_vs_golden(golden):
+    g = golden("linattn")
+    q, k, v = (torch.from_numpy(g[n])[0] for n in "qkv")  # [L,8,32], [S,8,32]
+    L, S = q.shape[0], k.shape[0]
+    Qf = torch.zeros(128, 256)
+    Qf[:L] = torch.nn.functional.elu(q.reshape(L, 256)) + 1
+    KV = torch.zeros(128, 512)
+    KV[:S, :256] = torch.nn.functional.elu(k.reshape(S, 256)) + 1
+    KV[:S, 256:] = v.reshape(S, 256)
+    KV[S:, :256] = 7.0  # padding rows must not leak into the reduction
+    KVd = dev(KV)
+    row0, clen = dev(torch.tensor([0, 0], dtype=torch.int32)), dev(torch.tensor([L, S], dtype=torch.int32))
+    kv = ops.kv_reduce(KVd, KVd[:, 256:], 512, 0, row0, clen, 1, 1, 1, 2)
+    out = ops.attn_apply(dev(Qf), 256, kv, dev(torch.tensor([0], dtype=torch.int32)), 1, clen, 128).cpu()
+    torch.testing.assert_close(out[:L].reshape(L, 8, 32), torch.from_numpy(g["out"])[0], rtol=2e-5, atol=2e-6)
+
+
+def test_kv_reduce_multichunk_vs_oracle():
+    rng = np.random.default_rng(1)
+    S = 1000  # 4 chunks, ragged tail
+    k = torch.from_numpy(rng.normal(size=(1, S, 8, 32)).astype(np.float32))
+    v = torch.from_numpy(rng.normal(size=(1, S, 8, 32)).astype(np.float32))
+    want = {}
+    O.linear_attention(k[:, :5], k, v, want)
+    buf = torch.zeros(1024, 512)
+    buf[:S, :256] = want["K"].reshape(S, 256)
+    buf[:S, 256:] = v.reshape(S, 256)
+    b = dev(buf)
+    kv = ops.kv_reduce(b, b[:, 256:], 512, 0, dev(torch.tensor([0], dtype=torch.int32)),
+                       dev(torch.tensor([S], dtype=torch.int32)), 0, 1, 4, 1).cpu()
+    kvt = kv[0, :, : 32 * 32].reshape(8, 32, 32)  # [h][v][d]
+    torch.testing.assert_close(kvt.permute(0, 2, 1), want["KV"][0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(kv[0, :, 32 * 32:], want["Ksum"][0], rtol=1e-5, atol=1e-4)
+
+
+# ----------------------------------------------------------------- A1-A6 whole forward pass
+def test_forward_vs_reference_golden(golden):
+    g = golden("e2e")
+    for seed, ns, nc, n, m, explicit in g["cases"]:
+        net = build_net(int(seed), int(ns), int(nc))
+        center = dev(g["center_%d" % seed]) if explicit else None
+        src_, imgs, tr = net(dev(g["src_%d" % seed]), dev(g["tgt_%d" % seed]), center, 1.0, False, False, None)
+        assert imgs is None and tr is None and src_.shape == (1, n, 3)
+        np.testing.assert_allclose(src_.cpu().numpy(), g["out_%d" % seed], rtol=2e-4, atol=5e-5,
+                                   err_msg="case seed=%d" % seed)
+
+
+def test_forward_batched_equals_single_pair():
+    net = build_net(5, 2, 2)
+    rng = np.random.default_rng(9)
+    sizes = [(200, 130), (1, 300), (129, 128), (640, 5)]
+    srcs = [dev(rng.uniform(-0.7, 0.7, size=(n, 3)).astype(np.float32)) for n, _ in sizes]
+    tgts = [dev(rng.uniform(-0.7, 0.7, size=(m, 3)).astype(np.float32)) for _, m in sizes]
+    cents = [dev(rng.uniform(-0.2, 0.2, size=3).astype(np.float32)) for _ in sizes]
+    batched = net.forward_batch(srcs, tgts, cents)
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    for i in range(len(sizes)):
+        single = net(srcs[i][None], tgts[i][None], cents[i].view(1, 1, 3))[0][0]
+        torch.testing.assert_close(batched[i], single, rtol=0, atol=0)  # same kernels, same order: bitwise
+        want = O.point_transformer_forward(srcs[i][None].cpu(), tgts[i][None].cpu(), sd, cents[i].view(1, 1, 3).cpu())[0]
+        torch.testing.assert_close(batched[i].cpu(), want, rtol=2e-4, atol=5e-5)
+
+
+# ------------------------------------------------------------------------------ A7 1-NN
+def test_nn_bit_exact_vs_reference_golden(golden):
+    from scream_amd.geometry import nn_search_pair
+    g, e = golden("nn"), golden("e2e")
+    for i, s in enumerate(g["e2e_s"]):
+        d, idx, valid = nn_search_pair(dev(e["out_23"][0]), dev(e["tgt_23"][0]), float(s), 0.1)
+        np.testing.assert_array_equal(idx.cpu().numpy(), g["e2e_idx_%d" % i])
+        np.testing.assert_array_equal(d.cpu().numpy(), g["e2e_d_%d" % i])
+    d, idx, valid = nn_search_pair(dev(g["big_src"][0]), dev(g["big_tgt"][0]), float(g["big_s"]), 0.1)
+    np.testing.assert_array_equal(idx.cpu().numpy(), g["big_idx"])  # incl. duplicate targets: lowest index wins
+    np.testing.assert_array_equal(d.cpu().numpy(), g["big_d"])
+    np.testing.assert_array_equal(valid.cpu().numpy(), g["big_valid"])
+
+
+def test_nn_bit_exact_full_size_and_packed():
+    """N = M ~ 5k (BASELINE config 2 size) and a packed multi-pair call with target-range splits."""
+    rng = np.random.default_rng(4)
+    pairs = [(5000, 5003, 0.31), (777, 4100, 1.7), (1, 1, 0.5), (2049, 1025, 0.9)]
+    q_list = [rng.uniform(-1, 1, size=(n, 3)).astype(np.float32) for n, _, _ in pairs]
+    r_list = [rng.uniform(-1, 1, size=(m, 3)).astype(np.float32) for _, m, _ in pairs]
+    q_row0 = np.cumsum([0] + [((n + 127) // 128) * 128 for n, _, _ in pairs])
+    r_row0 = np.cumsum([0] + [((m + 127) // 128) * 128 for _, m, _ in pairs])
+    q = np.zeros((q_row0[-1], 3), np.float32)
+    r = np.zeros((r_row0[-1], 3), np.float32)
+    for i in range(len(pairs)):
+        q[q_row0[i]: q_row0[i] + pairs[i][0]] = q_list[i]
+        r[r_row0[i]: r_row0[i] + pairs[i][1]] = r_list[i]
+    i32 = lambda a: dev(torch.tensor(np.asarray(a), dtype=torch.int32))
+    idx, dmin, valid = ops.nn_search(dev(q), dev(r), i32(q_row0[:-1]), i32([p[0] for p in pairs]), i32(r_row0[:-1]),
+                                     i32([p[1] for p in pairs]), dev(torch.tensor([p[2] for p in pairs])),
+                                     max(p[0] for p in pairs), max(p[1] for p in pairs), 0.01)
+    idx, dmin, valid = idx.cpu().numpy(), dmin.cpu().numpy(), valid.cpu().numpy()
+    for i, (n, m, s) in enumerate(pairs):
+        de, ie, _ = O.nn_search_exact(q_list[i], r_list[i], s)
+        sl = slice(q_row0[i], q_row0[i] + n)
+        np.testing.assert_array_equal(idx[sl], ie)
+        np.testing.assert_array_equal(dmin[sl], de)
+        np.testing.assert_array_equal(valid[sl].astype(bool), de < np.float32(0.01))
+        assert (idx[q_row0[i] + n: q_row0[i + 1]] == -1).all() and not valid[q_row0[i] + n: q_row0[i + 1]].any()
+
+
+def test_square_distance_dense_bit_exact():
+    from scream_amd.geometry import square_distance
+    rng = np.random.default_rng(6)
+    a = torch.from_numpy(rng.uniform(-1, 1, size=(2, 33, 3)).astype(np.float32))
+    b = torch.from_numpy(rng.uniform(-1, 1, size=(2, 300, 3)).astype(np.float32))
+    torch.testing.assert_close(square_distance(dev(a), dev(b)).cpu(), O.square_distance(a, b), rtol=0, atol=0)
+
+
+# --------------------------------------------------------------------------- A9/A10 Kabsch
+def test_rigid_transform_vs_reference_golden(golden):
+    from scream_amd.geometry import rigid_transform_3d
+    g = golden("kabsch")
+    for name in g["names"]:
+        name = str(name)
+        w = dev(g[name + "_w"].copy()) if name + "_w" in g else None
+        thr = float(g[name + "_thr"]) if name + "_thr" in g else 0
+        T = rigid_transform_3d(dev(g[name + "_A"]), dev(g[name + "_B"]), w, thr).cpu().numpy()
+        # BASELINE.json north_star: R|t within 1e-4 Frobenius of the reference CPU path
+        assert np.linalg.norm(T - g[name + "_T"]) < (1e-4 if name != "k3" else 5e-4), name
+        R = T[:, :3, :3].astype(np.float64)
+        np.testing.assert_allclose(R @ R.transpose(0, 2, 1), np.broadcast_to(np.eye(3), R.shape), atol=1e-6)
+        np.testing.assert_allclose(np.linalg.det(R), 1.0, atol=1e-6)
+        if w is not None:  # sub-threshold weights are zeroed in the caller's tensor (utils.py:151)
+            assert (w.cpu().numpy()[g[name + "_w"] < thr] == 0).all()
+    np.testing.assert_array_equal(rigid_transform_3d(dev(g["k0_A"]), dev(g["k0_B"])).cpu().numpy()[0], np.eye(4, dtype=np.float32))
+
+
+def test_kabsch_degenerate_inputs_stay_proper_rotations():
+    from scream_amd.geometry import rigid_transform_3d
+    rng = np.random.default_rng(8)
+    for K in (1, 2):  # rank-deficient H: rotation not unique in the reference either; must stay finite and proper
+        A = torch.from_numpy(rng.uniform(-1, 1, size=(1, K, 3)).astype(np.float32))
+        B = torch.from_numpy(rng.uniform(-1, 1, size=(1, K, 3)).astype(np.float32))
+        T = rigid_transform_3d(dev(A), dev(B)).cpu().numpy()[0].astype(np.float64)
+        assert np.isfinite(T).all()
+        np.testing.assert_allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-6)
+        np.testing.assert_allclose(np.linalg.det(T[:3, :3]), 1.0, atol=1e-6)
+
+
+def test_transformation_error_vs_reference_golden(golden):
+    from scream_amd.geometry import transformation_error
+    g = golden("pose_metrics")
+    P = g["poses"]
+    n = len(P)
+    Tp = dev(np.repeat(P, n, axis=0))
+    Tg = dev(np.tile(P, (n, 1, 1)))
+    re, te = ops.transformation_error_batched(Tp, Tg)
+    np.testing.assert_allclose(re.cpu().numpy().reshape(n, n), g["re"], atol=0.03)  # acos near 1 is ill conditioned in fp32
+    np.testing.assert_allclose(te.cpu().numpy().reshape(n, n), g["te"], rtol=1e-6, atol=1e-7)
+    r0, t0 = transformation_error(dev(P[0]), dev(P[3]))
+    assert r0.dim() == 0 and abs(r0.item() - g["re"][0, 3]) < 1e-3 and abs(t0.item() - g["te"][0, 3]) < 1e-6
+
+
+# --------------------------------------------------- whole pair A1-A10 at BASELINE config-2 size
+def test_register_pairs_full_size_vs_oracle():
+    """Two synthetic 3DMatch-like pairs (~5k points, voxel 0.0625) through forward -> 1-NN -> Kabsch -> RE/TE,
+    batched, against the oracle per pair.  src_pred is checked to tolerance; the discrete stage is checked
+    bit-exactly GIVEN the device src_pred (arg-min of near ties is only defined for
+    identical inputs), and R|t to 1e-4 Frobenius on the device correspondences."""
+    from scream_amd.data import normalize_pair
+    from scream_amd.geometry import register_batch
+    from scream_amd.packing import PackedBatch
+    net = build_net(0, 6, 6)
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    items = [normalize_pair(*make_3dmatch_pair(seed)[:3]) for seed in (1, 2)]
+    srcs = [dev(it[0]) for it in items]
+    tgts = [dev(it[1]) for it in items]
+    cents = [dev(it[3].reshape(3)) for it in items]  # src_center = trans^T (evaluate_3d_match.py:84)
+    batch = PackedBatch.from_pairs(srcs, tgts, cents)
+    src_pred = net.forward_packed(batch)
+    # GT-like prediction so that the threshold keeps a realistic number of correspondences
+    s = dev(torch.tensor([it[4] for it in items], dtype=torch.float32))
+    c = dev(torch.stack([it[5] for it in items]))
+    for i, it in enumerate(items):
+        n = it[0].shape[0]
+        want = O.point_transformer_forward(it[0][None], it[1][None], sd, it[3].reshape(1, 1, 3))[0]
+        got = batch.unpack_src(src_pred)[i].cpu()
+        assert got.shape == (n, 3)
+        torch.testing.assert_close(got, want, rtol=5e-4, atol=1e-4)
+    # replace the (random-weight) prediction by registered src + 1 cm noise: realistic K for gather/Kabsch
+    rng = np.random.default_rng(0)
+    pred = torch.zeros_like(src_pred)
+    for i, it in enumerate(items):
+        reg = (it[2] @ it[0].T + it[3]).T + torch.from_numpy(rng.normal(scale=0.01 * it[4], size=it[0].shape).astype(np.float32))
+        pred[int(batch.cloud_row0_host[i]): int(batch.cloud_row0_host[i]) + it[0].shape[0]] = dev(reg)
+    T, n_corr, idx, dmin, valid = register_batch(batch, pred, s, c, 0.1, "tgt")
+    for i, it in enumerate(items):
+        n = it[0].shape[0]
+        sl = slice(int(batch.cloud_row0_host[i]), int(batch.cloud_row0_host[i]) + n)
+        p_i = pred[sl].cpu()
+        d_o, idx_o, valid_o = O.nn_search(p_i[None], it[1][None], it[4], 0.1)
+        np.testing.assert_array_equal(idx[sl].cpu().numpy(), idx_o.numpy())
+        np.testing.assert_array_equal(dmin[sl].cpu().numpy(), d_o.numpy())
+        np.testing.assert_array_equal(valid[sl].cpu().numpy().astype(bool), valid_o.numpy())
+        assert int(n_corr[i]) == int(valid_o.sum()) > n // 10
+        A, Bc = O.gather_correspondences(it[0][None], it[1][None], p_i[None], idx_o, valid_o, it[4], it[5], "tgt")
+        T_o = O.rigid_transform_3d(A, Bc)[0]
+        assert torch.linalg.norm(T[i].cpu() - T_o).item() < 1e-4
+        Tgt = O.gt_pose_metric(it[2], it[3], it[4], it[5])
+        re_o, te_o = O.transformation_error(T_o, Tgt)
+        re, te = ops.transformation_error_batched(T[i:i + 1].contiguous(), dev(Tgt)[None].contiguous())
+        assert abs(re.item() - re_o.item()) < 0.05 and abs(te.item() - te_o.item()) < 1e-4
