@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: registration pairs/sec on synthetic 3DMatch_test-like clouds (BASELINE.json
+configs[1]: voxel 0.0625 m, ~5k points per cloud, batch-of-pairs = 32 per GPU).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One *step* = the hot path A1-A10 over one batch of 32 pairs per GPU, inputs resident
+in HBM: PointTransformer forward -> thresholded 1-NN -> fused gather + Kabsch -> RE/TE (+ the all-gather
+of per-pair metric rows when N > 1, the path's only collective).  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     -- the fp32-MFMA GEMM kernel (all epilogue instantiations pooled; per-instantiation rows in
+                  "by_kernel" so they can be matched against profiles/*kernel_stats*): algorithmic flops
+                  (true, unpadded token counts) / summed launch time, measured live with HIP events on the
+                  launch stream inside the timed region (scream_trace_*), against the 157.3 TFLOP/s fp32
+                  matrix peak of MI355X_MICROARCH.md.
+  cpu_baseline -- the CPU oracle (oracle/scream_ref.py, a PyTorch-CPU restatement validated against the
+                  reference) on a bounded sample of the same pairs, on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PAIRS_PER_GPU = 32
+PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+GEMM_NAMES = {0: "gemm_f32_kernel<EPI_NONE>", 1: "gemm_f32_kernel<EPI_ELU1> (q/k/v projections)",
+              2: "gemm_f32_kernel<EPI_RELU> (FFN 256->1024)", 3: "gemm_f32_kernel<EPI_BIAS_RELU> (coor_mlp)",
+              4: "gemm_f32_kernel<EPI_RES_LN> (merge, FFN 1024->256 + residual + LayerNorm)",
+              100: "pe_embed_ln_kernel", 101: "kv_partial_kernel + kv_final_kernel", 102: "attn_apply_kernel",
+              103: "coor_head_kernel"}
+
+
+def _gen(seed):
+    from scream_amd.data import normalize_pair
+    from scream_amd.synthetic import make_3dmatch_pair
+    src, tgt, T, idx, cov, scene = make_3dmatch_pair(seed)
+    return normalize_pair(src, tgt, T)
+
+
+def make_items(seeds, n_proc=0):
+    """Seeded synthetic pairs; generated in worker processes BEFORE this process touches the GPU
+    (--gen-procs 1 keeps it in-process, e.g. under rocprofv3 whose preload initialises the GPU first)."""
+    import multiprocessing as mp
+    if n_proc <= 0:
+        n_proc = max(1, min(8, len(os.sched_getaffinity(0)) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    if n_proc == 1:
+        return [_gen(s) for s in seeds]
+    with mp.get_context("fork").Pool(n_proc) as pool:
+        return pool.map(_gen, seeds)
+
+
+def gemm_flops_per_pair(n, m, d=256):
+    """stem 6 x 24 d^2 (N+M); src-self 6 x 24 d^2 N; cross 6 x (20 N + 4 M) d^2; coor_mlp 4 N d^2 + 6 d N."""
+    return d * d * (412 * n + 168 * m) + 6 * d * n
+
+
+def cpu_baseline(items, sd, max_pairs, budget_s=25.0):
+    import torch
+    from oracle import scream_ref as O  # checker, timed here as the reported CPU baseline only
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    done, t_total = 0, 0.0
+    with torch.no_grad():
+        O.register_pair(items[0][0][None, :256], items[0][1][None, :256], items[0][2][None], items[0][3][None],
+                        items[0][4], items[0][5], sd)  # warm the thread pool / allocator
+        for it in items[:max_pairs]:
+            t0 = time.perf_counter()
+            O.register_pair(it[0][None], it[1][None], it[2][None], it[3][None], it[4], it[5], sd)
+            t_total += time.perf_counter() - t0
+            done += 1
+            if t_total > budget_s:
+                break
+    return {"value": round(done / t_total, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d of the step's %d synthetic pairs, oracle/scream_ref.register_pair (A1-A10, fp32, torch-CPU %d threads), %.1f s"
+                      % (done, len(items), cores, t_total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gen-procs", type=int, default=0, help="worker processes for synthetic data (0 = auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+
+    B = args.pairs
+    items = make_items([rank * B + i for i in range(B)], args.gen_procs)  # before any GPU call (fork safety)
+
+    import torch
+    import torch.distributed as tdist
+    from scream_amd import _lib, ops
+    from scream_amd import dist as sdist
+    from scream_amd.evaluate import gt_pose_metric
+    from scream_amd.geometry import register_batch
+    from scream_amd.model import PointTransformer
+    from scream_amd.packing import PackedBatch
+    from scream_amd.synthetic import make_state_dict
+
+    rank, world, local = sdist.init_from_env("nccl")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    lib = _lib.load()
+
+    sd = make_state_dict(0, 256, 6, 6)
+    net = PointTransformer(256, 6, 6)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+
+    batch = PackedBatch.from_pairs([it[0].to(dev) for it in items], [it[1].to(dev) for it in items],
+                                   [it[3].reshape(3).to(dev) for it in items])
+    s = torch.tensor([it[4] for it in items], dtype=torch.float32, device=dev)
+    c = torch.stack([it[5] for it in items]).to(dev)
+    T_gt = torch.stack([gt_pose_metric(it[2], it[3], it[4], it[5]) for it in items]).to(dev)
+    pair_ids = torch.arange(rank * B, (rank + 1) * B, device=dev, dtype=torch.float32)
+    gathered = [torch.empty(B, sdist.ROW_WIDTH, device=dev) for _ in range(world)] if world > 1 else None
+
+    def step(trace=None):
+        src_pred = net.forward_packed(batch, trace=trace)                           # A1-A6
+        T, n_corr, idx, dmin, valid = register_batch(batch, src_pred, s, c, 0.1)    # A7-A9
+        re, te = ops.transformation_error_batched(T, T_gt)                          # A10
+        if world > 1:  # the path's only exchange: per-pair metric rows
+            rows = torch.zeros(B, sdist.ROW_WIDTH, device=dev)
+            rows[:, 0], rows[:, 4], rows[:, 5] = pair_ids, re, te
+            tdist.all_gather(gathered, rows)
+        return re, te, n_corr
+
+    def fence():
+        if world > 1:
+            tdist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    cap = 200 * max(args.steps, 1)
+    trace = lib.scream_trace_create(cap)
+    assert trace, "scream_trace_create failed"
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(trace)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel times recorded inside the timed region ------------------------------------
+    ms = (C.c_float * cap)()
+    kind = (C.c_int32 * cap)()
+    mm = (C.c_int64 * cap)()
+    nn = (C.c_int32 * cap)()
+    kk = (C.c_int32 * cap)()
+    cnt = lib.scream_trace_read(trace, cap, ms, kind, mm, nn, kk)
+    assert cnt > 0, "trace empty"
+    lib.scream_trace_destroy(trace)
+    by = {}
+    for i in range(cnt):
+        e = by.setdefault(kind[i], {"launches": 0, "ms": 0.0, "padded_flops": 0.0})
+        e["launches"] += 1
+        e["ms"] += ms[i]
+        e["padded_flops"] += 2.0 * mm[i] * nn[i] * kk[i]
+    gemm_ms = sum(v["ms"] for k_, v in by.items() if k_ < 100)
+    gemm_launches = sum(v["launches"] for k_, v in by.items() if k_ < 100)
+    rows_true = sum(batch.src_len) + sum(batch.tgt_len)
+    pad_eff = rows_true / batch.rows_total
+    algo_flops_step = sum(gemm_flops_per_pair(n, m) for n, m in zip(batch.src_len, batch.tgt_len))
+    achieved = algo_flops_step * args.steps / (gemm_ms * 1e-3) / 1e12
+    by_kernel = []
+    for k_, v in sorted(by.items()):
+        row = {"kernel": GEMM_NAMES.get(k_, str(k_)), "launches": v["launches"],
+               "avg_ms": round(v["ms"] / v["launches"], 4), "share_of_step": round(v["ms"] / (elapsed * 1e3), 4)}
+        if k_ < 100:
+            row["tflops_algorithmic"] = round(v["padded_flops"] * pad_eff / (v["ms"] * 1e-3) / 1e12, 2)
+        by_kernel.append(row)
+
+    if rank == 0:
+        total_pairs = B * world * args.steps
+        out = {
+            "metric": "registration pairs/sec", "value": round(total_pairs / elapsed, 3), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: synthetic 3DMatch_test-like pairs, voxel 0.0625 m, "
+                                   "~5k points/cloud, batch-of-pairs=%d per GPU, A1-A10 per pair "
+                                   "(forward 6+6 layers d_model 256, 1-NN thresh 0.1, Kabsch, RE/TE), random-init weights seed 0" % B,
+                       "pairs_per_step_per_gpu": B, "mean_src_points": round(float(np.mean(batch.src_len)), 1),
+                       "mean_tgt_points": round(float(np.mean(batch.tgt_len)), 1), "parallelism": "dp%d (pairs sharded, metric-row all-gather)" % world},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32; all epilogue instantiations)",
+                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                         "launches": gemm_launches, "avg_ms": round(gemm_ms / gemm_launches, 4),
+                         "algorithmic_gflop_per_step": round(algo_flops_step / 1e9, 1),
+                         "row_padding_efficiency": round(pad_eff, 4), "by_kernel": by_kernel},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(items, sd, 16)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -128,9 +128,21 @@ int64_t scream_forward_workspace_bytes(int64_t rows_src, int64_t rows_total, int
                                        int32_t max_chunks);
 
 /* src_pred [rows_src,3] (padding rows hold don't-care values).  If feats_out != NULL the final
- * source features [rows_src,256] are copied there (test hook). */
+ * source features [rows_src,256] are copied there (test hook).  trace: NULL, or a handle from
+ * scream_trace_create -- then every kernel group of the forward is bracketed by HIP events on `stream`. */
 int scream_forward(const scream_model_t* model, const scream_batch_t* batch, void* workspace,
-                   int64_t workspace_bytes, float* src_pred, float* feats_out, void* stream);
+                   int64_t workspace_bytes, float* src_pred, float* feats_out, void* trace,
+                   void* stream);
+
+/* Per-launch timing for bench.py's roofline leg.  A trace owns 2*capacity HIP events; records beyond
+ * capacity are dropped.  scream_trace_read (after the stream has been synchronised) fills, per record,
+ * the elapsed ms, the kind (a SCREAM_EPI_* value for a GEMM with its M, N, K; 100 = embed, 101 = K^T V
+ * reduce, 102 = attention apply, 103 = 256->3 head, with M = rows) and returns the record count. */
+void* scream_trace_create(int32_t capacity);
+void scream_trace_destroy(void* trace);
+int scream_trace_reset(void* trace);
+int scream_trace_read(void* trace, int32_t max_records, float* ms, int32_t* kind, int64_t* m,
+                      int32_t* n, int32_t* k);
 
 /* ---- A7: thresholded 1-NN of every query point in its pair's target cloud.
  * Replaces square_distance(src_pred / s, tgt / s)[0].min(dim=1) and the threshold compare at

@@ -6,6 +6,8 @@
 //     (pointnet.py:50-52), run as one launch set over every row of every cloud of every pair;
 //   * the cross stage (pointnet.py:53-57) runs over the source prefix only, the target features stay
 //     frozen in the rows the stem left them in.
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -38,51 +40,148 @@ Workspace carve(void* base, int64_t rows_total, int32_t n_pairs, int32_t max_chu
     return w;
 }
 
+// Optional per-launch timing (bench.py's roofline leg): HIP events recorded on the launch stream around
+// every kernel group of the forward.  Owned by the caller through an opaque handle; no global state.
+struct Trace {
+    std::vector<hipEvent_t> ev;  // 2 per record
+    std::vector<int32_t> kind, n, k;
+    std::vector<int64_t> m;
+    int count = 0;
+    int capacity = 0;
+};
+
+struct Scope {  // records start on construction, stop on destruction
+    Trace* t;
+    int slot = -1;
+    hipStream_t st;
+    Scope(Trace* t_, int kind, int64_t m, int n, int k, void* stream) : t(t_), st(as_stream(stream)) {
+        if (!t || t->count >= t->capacity) return;
+        slot = t->count++;
+        t->kind[slot] = kind;
+        t->m[slot] = m;
+        t->n[slot] = n;
+        t->k[slot] = k;
+        (void)hipEventRecord(t->ev[2 * slot], st);
+    }
+    ~Scope() {
+        if (slot >= 0) (void)hipEventRecord(t->ev[2 * slot + 1], st);
+    }
+};
+
 #define TRY(call)                 \
     do {                          \
         int rc_ = (call);         \
         if (rc_ != 0) return rc_; \
     } while (0)
 
+enum { TR_EMBED = 100, TR_KV_REDUCE = 101, TR_ATTN_APPLY = 102, TR_COOR_HEAD = 103 };
+
+struct Ctx {
+    void* st;
+    Trace* tr;
+};
+
+int gemm(const Ctx& c, const float* A, int64_t lda, const float* W, float* C, int64_t ldc, int64_t M, int N, int K,
+         int epi, int n_act, const float* bias, const float* res, const float* g, const float* b) {
+    Scope sc(c.tr, epi, M, N, K, c.st);
+    return scream_gemm_f32(A, lda, W, C, ldc, M, N, K, epi, n_act, bias, res, D, g, b, c.st);
+}
+
 // merge + norm1 + FFN + norm2 (models/transformer.py:83-88); x is the block input (residual of BOTH norms).
-int mha_tail(const scream_layer_t& L, const Workspace& w, const float* x, float* y, int64_t rows, void* st) {
-    TRY(scream_gemm_f32(w.att, D, L.wm, w.m1, D, rows, D, D, SCREAM_EPI_RES_LN, 0, nullptr, x, D, L.g1, L.b1, st));
-    TRY(scream_gemm_f32(w.m1, D, L.w1, w.hid, 4 * D, rows, 4 * D, D, SCREAM_EPI_RELU, 0, nullptr, nullptr, 0, nullptr,
-                        nullptr, st));
-    TRY(scream_gemm_f32(w.hid, 4 * D, L.w2, y, D, rows, D, 4 * D, SCREAM_EPI_RES_LN, 0, nullptr, x, D, L.g2, L.b2, st));
+int mha_tail(const Ctx& c, const scream_layer_t& L, const Workspace& w, const float* x, float* y, int64_t rows) {
+    TRY(gemm(c, w.att, D, L.wm, w.m1, D, rows, D, D, SCREAM_EPI_RES_LN, 0, nullptr, x, L.g1, L.b1));
+    TRY(gemm(c, w.m1, D, L.w1, w.hid, 4 * D, rows, 4 * D, D, SCREAM_EPI_RELU, 0, nullptr, nullptr, nullptr, nullptr));
+    TRY(gemm(c, w.hid, 4 * D, L.w2, y, D, rows, D, 4 * D, SCREAM_EPI_RES_LN, 0, nullptr, x, L.g2, L.b2));
     return 0;
 }
 
 // Self attention over rows [0, rows) whose clouds are [0, n_clouds)  (transformer.py:74-90 with q = k = v).
-int mha_self(const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x, float* y,
-             int64_t rows, int32_t n_clouds, void* st) {
-    TRY(scream_gemm_f32(x, D, L.wqkv, w.qkv, 3 * D, rows, 3 * D, D, SCREAM_EPI_ELU1, 2 * D, nullptr, nullptr, 0,
-                        nullptr, nullptr, st));
-    TRY(scream_kv_reduce(w.qkv + D, w.qkv + 2 * D, 3 * D, 0, b.cloud_row0, b.cloud_len, 0, n_clouds, b.max_chunks,
-                         w.kvp, w.kv, st));
-    TRY(scream_attn_apply(w.qkv, 3 * D, w.kv, b.tile_cloud, 0, b.cloud_len, w.att, D, rows, st));
-    return mha_tail(L, w, x, y, rows, st);
+int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x,
+             float* y, int64_t rows, int32_t n_clouds) {
+    TRY(gemm(c, x, D, L.wqkv, w.qkv, 3 * D, rows, 3 * D, D, SCREAM_EPI_ELU1, 2 * D, nullptr, nullptr, nullptr, nullptr));
+    {
+        Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
+        TRY(scream_kv_reduce(w.qkv + D, w.qkv + 2 * D, 3 * D, 0, b.cloud_row0, b.cloud_len, 0, n_clouds, b.max_chunks,
+                             w.kvp, w.kv, c.st));
+    }
+    {
+        Scope sc(c.tr, TR_ATTN_APPLY, rows, 0, 0, c.st);
+        TRY(scream_attn_apply(w.qkv, 3 * D, w.kv, b.tile_cloud, 0, b.cloud_len, w.att, D, rows, c.st));
+    }
+    return mha_tail(c, L, w, x, y, rows);
 }
 
 // Cross attention: queries from the source rows, keys/values from the frozen target rows (transformer.py:130).
-int mha_cross(const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x_src,
-              const float* x_tgt, float* y, void* st) {
+int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x_src,
+              const float* x_tgt, float* y) {
     const int64_t rs = b.rows_src, rt = b.rows_total - b.rows_src;
     float* qb = w.qkv;             // [rs, 256]
     float* kvb = w.qkv + rs * D;   // [rt, 512]
-    TRY(scream_gemm_f32(x_src, D, L.wqkv, qb, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, 0, nullptr, nullptr, st));
-    TRY(scream_gemm_f32(x_tgt, D, L.wqkv + (int64_t)D * D, kvb, 2 * D, rt, 2 * D, D, SCREAM_EPI_ELU1, D, nullptr,
-                        nullptr, 0, nullptr, nullptr, st));
-    TRY(scream_kv_reduce(kvb, kvb + D, 2 * D, rs, b.cloud_row0, b.cloud_len, b.n_pairs, b.n_pairs, b.max_chunks, w.kvp,
-                         w.kv, st));
-    TRY(scream_attn_apply(qb, D, w.kv, b.tile_cloud, b.n_pairs, b.cloud_len, w.att, D, rs, st));
-    return mha_tail(L, w, x_src, y, rs, st);
+    TRY(gemm(c, x_src, D, L.wqkv, qb, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr));
+    TRY(gemm(c, x_tgt, D, L.wqkv + (int64_t)D * D, kvb, 2 * D, rt, 2 * D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr,
+             nullptr, nullptr));
+    {
+        Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
+        TRY(scream_kv_reduce(kvb, kvb + D, 2 * D, rs, b.cloud_row0, b.cloud_len, b.n_pairs, b.n_pairs, b.max_chunks,
+                             w.kvp, w.kv, c.st));
+    }
+    {
+        Scope sc(c.tr, TR_ATTN_APPLY, rs, 0, 0, c.st);
+        TRY(scream_attn_apply(qb, D, w.kv, b.tile_cloud, b.n_pairs, b.cloud_len, w.att, D, rs, c.st));
+    }
+    return mha_tail(c, L, w, x_src, y, rs);
 }
 
 }  // namespace
 
-extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi1"; }
-extern "C" int scream_abi_version(void) { return 1; }
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi2"; }
+extern "C" int scream_abi_version(void) { return 2; }
+
+extern "C" void* scream_trace_create(int32_t capacity) {
+    if (capacity <= 0) return nullptr;
+    Trace* t = new Trace();
+    t->capacity = capacity;
+    t->ev.resize(2 * (size_t)capacity);
+    t->kind.resize(capacity);
+    t->n.resize(capacity);
+    t->k.resize(capacity);
+    t->m.resize(capacity);
+    for (auto& e : t->ev) {
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete t;
+            return nullptr;
+        }
+    }
+    return t;
+}
+
+extern "C" void scream_trace_destroy(void* trace) {
+    Trace* t = reinterpret_cast<Trace*>(trace);
+    if (!t) return;
+    for (auto& e : t->ev) (void)hipEventDestroy(e);
+    delete t;
+}
+
+extern "C" int scream_trace_reset(void* trace) {
+    SCREAM_REQUIRE(trace, SCREAM_EINVAL);
+    reinterpret_cast<Trace*>(trace)->count = 0;
+    return 0;
+}
+
+extern "C" int scream_trace_read(void* trace, int32_t max_records, float* ms, int32_t* kind, int64_t* m, int32_t* n,
+                                 int32_t* k) {
+    SCREAM_REQUIRE(trace && ms && kind && m && n && k && max_records >= 0, SCREAM_EINVAL);
+    Trace* t = reinterpret_cast<Trace*>(trace);
+    const int cnt = t->count < max_records ? t->count : max_records;
+    for (int i = 0; i < cnt; ++i) {
+        if (hipEventElapsedTime(&ms[i], t->ev[2 * i], t->ev[2 * i + 1]) != hipSuccess) return SCREAM_EINVAL;
+        kind[i] = t->kind[i];
+        m[i] = t->m[i];
+        n[i] = t->n[i];
+        k[i] = t->k[i];
+    }
+    return cnt;
+}
 
 extern "C" int64_t scream_forward_workspace_bytes(int64_t rows_src, int64_t rows_total, int32_t n_pairs,
                                                   int32_t max_chunks) {
@@ -91,7 +190,7 @@ extern "C" int64_t scream_forward_workspace_bytes(int64_t rows_src, int64_t rows
 }
 
 extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t* batch, void* workspace,
-                              int64_t workspace_bytes, float* src_pred, float* feats_out, void* stream) {
+                              int64_t workspace_bytes, float* src_pred, float* feats_out, void* trace, void* stream) {
     SCREAM_REQUIRE(model && batch && workspace && src_pred, SCREAM_EINVAL);
     const scream_model_t& m = *model;
     const scream_batch_t& b = *batch;
@@ -102,13 +201,17 @@ extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t*
     uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
     const Workspace w = carve(reinterpret_cast<void*>(base), b.rows_total, b.n_pairs, b.max_chunks);
     SCREAM_REQUIRE((int64_t)(base - reinterpret_cast<uintptr_t>(workspace)) + w.bytes <= workspace_bytes, SCREAM_EINVAL);
+    const Ctx c{stream, reinterpret_cast<Trace*>(trace)};
 
     const int64_t rs = b.rows_src, ra = b.rows_total;
-    TRY(scream_pe_embed_ln(b.xyz, b.tile_cloud, b.center, m.dim_t, m.emb_w, m.emb_b, m.pre_g, m.pre_b, w.x0, ra, stream));
+    {
+        Scope sc(c.tr, TR_EMBED, ra, 0, 0, stream);
+        TRY(scream_pe_embed_ln(b.xyz, b.tile_cloud, b.center, m.dim_t, m.emb_w, m.emb_b, m.pre_g, m.pre_b, w.x0, ra, stream));
+    }
     float* cur = w.x0;
     float* nxt = w.x1;
     for (int i = 0; i < m.n_self; ++i) {  // pointnet.py:50-52
-        TRY(mha_self(m.layers_host[i], b, w, cur, nxt, ra, 2 * b.n_pairs, stream));
+        TRY(mha_self(c, m.layers_host[i], b, w, cur, nxt, ra, 2 * b.n_pairs));
         float* t = cur;
         cur = nxt;
         nxt = t;
@@ -117,18 +220,21 @@ extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t*
     for (int i = 0; i < 2 * m.n_cross; ++i) {  // pointnet.py:53-57
         const scream_layer_t& L = m.layers_host[m.n_self + i];
         if (i % 2 == 0) {
-            TRY(mha_self(L, b, w, cur, nxt, rs, b.n_pairs, stream));
+            TRY(mha_self(c, L, b, w, cur, nxt, rs, b.n_pairs));
         } else {
-            TRY(mha_cross(L, b, w, cur, x_tgt, nxt, stream));
+            TRY(mha_cross(c, L, b, w, cur, x_tgt, nxt));
         }
         float* t = cur;
         cur = nxt;
         nxt = t;
     }
     // coor_mlp, pointnet.py:27-33,60
-    TRY(scream_gemm_f32(cur, D, m.c0_w, w.m1, D, rs, D, D, SCREAM_EPI_BIAS_RELU, 0, m.c0_b, nullptr, 0, nullptr, nullptr, stream));
-    TRY(scream_gemm_f32(w.m1, D, m.c2_w, w.att, D, rs, D, D, SCREAM_EPI_BIAS_RELU, 0, m.c2_b, nullptr, 0, nullptr, nullptr, stream));
-    TRY(scream_coor_head(w.att, m.c4_w, m.c4_b, src_pred, rs, stream));
+    TRY(gemm(c, cur, D, m.c0_w, w.m1, D, rs, D, D, SCREAM_EPI_BIAS_RELU, 0, m.c0_b, nullptr, nullptr, nullptr));
+    TRY(gemm(c, w.m1, D, m.c2_w, w.att, D, rs, D, D, SCREAM_EPI_BIAS_RELU, 0, m.c2_b, nullptr, nullptr, nullptr));
+    {
+        Scope sc(c.tr, TR_COOR_HEAD, rs, 0, 0, stream);
+        TRY(scream_coor_head(w.att, m.c4_w, m.c4_b, src_pred, rs, stream));
+    }
     if (feats_out) {
         hipError_t e = hipMemcpyAsync(feats_out, cur, (size_t)rs * D * sizeof(float), hipMemcpyDeviceToDevice,
                                       as_stream(stream));

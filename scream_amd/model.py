@@ -127,7 +127,7 @@ class PointTransformer(nn.Module):
         return self._packed
 
     # ------------------------------------------------------------------ batched entry
-    def forward_packed(self, batch: PackedBatch, return_feats: bool = False):
+    def forward_packed(self, batch: PackedBatch, return_feats: bool = False, trace=None):
         """A1-A6 for every pair of the batch in one C-ABI call; returns src_pred packed [rows_src, 3]."""
         mt, _layers, _keep = self._pack_weights()
         lib = _lib.load()
@@ -145,7 +145,7 @@ class PointTransformer(nn.Module):
         feats = torch.empty(batch.rows_src, D_MODEL, device=dev, dtype=torch.float32) if return_feats else None
         _lib.check(lib.scream_forward(C.byref(mt), C.byref(bt), self._ws.data_ptr(), self._ws.numel(),
                                       src_pred.data_ptr(), feats.data_ptr() if return_feats else None,
-                                      ops._stream()), "scream_forward")
+                                      trace, ops._stream()), "scream_forward")
         return (src_pred, feats) if return_feats else src_pred
 
     def forward_batch(self, srcs: Sequence[torch.Tensor], tgts: Sequence[torch.Tensor],
