@@ -65,7 +65,8 @@ def gemm_flops_per_pair(n, m, d=256):
 def cpu_baseline(items, sd, max_pairs, budget_s=25.0):
     import torch
     from oracle import scream_ref as O  # checker, timed here as the reported CPU baseline only
-    cores = len(os.sched_getaffinity(0))
+    # the GPU box exposes every host core in the affinity mask but one GPU's share of the host is 16 cores
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("SCREAM_CPU_BASELINE_THREADS", "16")))
     torch.set_num_threads(cores)
     done, t_total = 0, 0.0
     with torch.no_grad():
