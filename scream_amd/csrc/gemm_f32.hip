@@ -6,16 +6,24 @@
 // same sense as the reference's sgemm (only the summation order differs).
 //
 // Geometry (MI355X_MICROARCH.md: 64 FLOP/clk/SIMD for f32 MFMA, 160 KiB LDS/CU):
-//   block tile 128 x 256, BK = 32, 256 threads = 4 waves as 2(M) x 2(N); wave tile 64 x 128
-//   = 2 x 4 MFMA tiles of 32x32 -> 128 accumulator registers; 2 blocks per CU (54 KiB LDS each)
+//   block tile 128 x 256, BK = 32, 256 threads = 4 waves stacked in M; wave tile 32 x 256
+//   = 8 MFMA tiles of 32x32 -> 128 accumulator registers; 2 blocks per CU (54 KiB LDS each)
 //   so the second block's MFMAs cover the first block's staging/barriers.
 //   Both operands are K-contiguous.  A k-chunk of 8 is split so that lane (r, half) holds
 //   k = 4*half .. 4*half+3 of row r for BOTH operands: the contraction index is a dummy, so any
 //   k permutation shared by A and W is legal, and it lets every fragment be one ds_read_b128.
 //   LDS rows are padded to 36 floats: the four 16-lane groups of a ds_read_b128 then hit 16
-//   distinct 4-bank slots (36 r mod 64 is a bijection on r mod 16) -> conflict free.
+//   distinct 4-bank slots (36 r mod 64 is a bijection on r mod 16) -> conflict free (measured:
+//   SQ_LDS_BANK_CONFLICT = 0, profiles/r01_v1_bench_pmc_mfma_lds.txt).
 //   Staging is global -> registers (issued before the MFMAs of the current tile) -> LDS
 //   (written after them); fp32 MFMA is slow enough (64 cycles each) that this is fully hidden.
+//   Epilogue: a wave owns whole 256-wide rows, so LayerNorm statistics never leave the wave, and
+//   the accumulators go through a wave-private LDS slab (8 rows at a time) to turn the MFMA layout
+//   (lane = column) into row-major float4 per lane: every residual load and output store is one
+//   full 1 KiB row per wave instruction (v1 issued 128 dword stores per lane and lost ~25 % of the
+//   MFMA time to store issue).
+//   Blocks are renumbered so that the N-tiles of one M-tile run back to back on ONE XCD (shared A
+//   tile in that XCD's L2) -- placement only changes speed, never results.
 #include "common.h"
 
 namespace {
@@ -35,6 +43,8 @@ struct EpiArgs {
     const float* beta;
 };
 
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
 template <int EPI>
 __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                              const float* __restrict__ W,
@@ -47,10 +57,15 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
     const int r = lane & 31, half = lane >> 5;
-    const int64_t mt = blockIdx.x / n_tiles;
-    const int nt = blockIdx.x % n_tiles;
+
+    // XCD-aware renumbering (bijective for any grid size): blocks b, b+8, b+16, ... share an XCD, give them
+    // consecutive tiles so the n_tiles blocks that read one A tile hit the same L2.
+    const unsigned nb = gridDim.x, bid = blockIdx.x;
+    const unsigned xcd = bid & 7u, q = nb >> 3, rem = nb & 7u;
+    const unsigned tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    const int64_t mt = tile / n_tiles;
+    const int nt = tile % n_tiles;
     const int64_t m0 = mt * BM;
     const int n0 = nt * BN;
 
@@ -62,17 +77,15 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
 
     f32x4 ra[4], rb[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ga + (int64_t)(32 * i) * lda);
+    for (int i = 0; i < 4; ++i) ra[i] = ld4(ga + (int64_t)(32 * i) * lda);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rb[i] = *reinterpret_cast<const f32x4*>(gw + (int64_t)(32 * i) * K);
+    for (int i = 0; i < 8; ++i) rb[i] = ld4(gw + (int64_t)(32 * i) * K);
 
-    f32x16 acc[2][4];
+    f32x16 acc[8];
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tn = 0; tn < 8; ++tn)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[tn][e] = 0.f;
 
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(As + lds_st + 32 * i * LDS_LD) = ra[i];
@@ -80,8 +93,8 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
     for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(Bs + lds_st + 32 * i * LDS_LD) = rb[i];
     __syncthreads();
 
-    const float* a_frag = As + (wm * 64 + r) * LDS_LD + half * 4;
-    const float* b_frag = Bs + (wn * 128 + r) * LDS_LD + half * 4;
+    const float* a_frag = As + (wave * 32 + r) * LDS_LD + half * 4;
+    const float* b_frag = Bs + r * LDS_LD + half * 4;
     const int KT = K / BK;
     for (int kt = 0; kt < KT; ++kt) {
         const bool more = kt + 1 < KT;
@@ -89,24 +102,33 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
             ga += BK;
             gw += BK;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(ga + (int64_t)(32 * i) * lda);
+            for (int i = 0; i < 4; ++i) ra[i] = ld4(ga + (int64_t)(32 * i) * lda);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) rb[i] = *reinterpret_cast<const f32x4*>(gw + (int64_t)(32 * i) * K);
+            for (int i = 0; i < 8; ++i) rb[i] = ld4(gw + (int64_t)(32 * i) * K);
         }
+        // 8 half-chunks (4 k-chunks x 2 halves of the 8 N-tiles), software pipelined: the LDS reads of
+        // half-chunk h+1 are issued BEFORE the 16 MFMAs of half-chunk h, into the other fragment set.
+        f32x4 fa[2], fb[2][4];
+        fa[0] = ld4(a_frag);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            f32x4 af[2], bf[4];
+        for (int t = 0; t < 4; ++t) fb[0][t] = ld4(b_frag + t * 32 * LDS_LD);
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) af[tm] = *reinterpret_cast<const f32x4*>(a_frag + tm * 32 * LDS_LD + kk * 8);
+        for (int hc = 0; hc < 8; ++hc) {
+            const int cur = hc & 1, nxt = cur ^ 1;
+            if (hc + 1 < 8) {
+                const int kk = (hc + 1) >> 1, th = (hc + 1) & 1;
+                fa[nxt] = ld4(a_frag + kk * 8);
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) bf[tn] = *reinterpret_cast<const f32x4*>(b_frag + tn * 32 * LDS_LD + kk * 8);
+                for (int t = 0; t < 4; ++t) fb[nxt][t] = ld4(b_frag + (th * 4 + t) * 32 * LDS_LD + kk * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks these reads to just before their use
+            const int th0 = hc & 1;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][j], bf[tn][j], acc[tm][tn], 0, 0, 0);
+                for (int t = 0; t < 4; ++t)
+                    acc[th0 * 4 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][j], fb[cur][t][j], acc[th0 * 4 + t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads above, the next half-chunk's below
         }
         __syncthreads();
         if (more) {
@@ -118,93 +140,68 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
         }
     }
 
-    // ------------------------------------------------------------------ epilogue
-    // acc[tm][tn][e]: row = wm*64 + tm*32 + mfma32_row(e, half), col = wn*128 + tn*32 + r
-    const int row_w = wm * 64;
-    const int col_w = n0 + wn * 128 + r;
-
+    // ------------------------------------------------------------------ epilogue (wave-private)
+    // acc[tn][e]: row = wave*32 + mfma32_row(e, half), col = tn*32 + r.  The loop above ended on a barrier, so
+    // the staging LDS is free: each wave takes its own slab and never synchronises with the others again.
+    constexpr int SLAB_LD = 260;  // 256 + 4 floats
+    float* slab = smem + wave * (8 * SLAB_LD);  // 8 rows; 4 x 8320 B <= 55296 B
+    const int col = n0 + lane * 4;
+    f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};  // bias | gamma, beta
+    if (EPI == SCREAM_EPI_BIAS_RELU) p0 = ld4(ep.bias + col);
     if (EPI == SCREAM_EPI_RES_LN) {
-        float* red1 = smem;        // [2][128] row sums per N-half (smem is free: loop ended on a barrier)
-        float* red2 = smem + 256;  // [2][128] centred sums of squares
-        float g[4], b[4];
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            g[tn] = ep.gamma[col_w + tn * 32];
-            b[tn] = ep.beta[col_w + tn * 32];
-        }
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rl = row_w + tm * 32 + mfma32_row(e, half);
-                const float* rp = ep.residual + (m0 + rl) * ep.ldr + col_w;
-                float s = 0.f;
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    acc[tm][tn][e] += rp[tn * 32];
-                    s += acc[tm][tn][e];
-                }
-                s = half_wave_sum(s);
-                if (r == 0) red1[wn * 128 + rl] = s;
-            }
-        __syncthreads();
-        float mean[2][16];
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rl = row_w + tm * 32 + mfma32_row(e, half);
-                mean[tm][e] = (red1[rl] + red1[128 + rl]) * (1.0f / 256.0f);
-                float s = 0.f;
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    const float d = acc[tm][tn][e] - mean[tm][e];
-                    s += d * d;
-                }
-                s = half_wave_sum(s);
-                if (r == 0) red2[wn * 128 + rl] = s;
-            }
-        __syncthreads();
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rl = row_w + tm * 32 + mfma32_row(e, half);
-                const float var = (red2[rl] + red2[128 + rl]) * (1.0f / 256.0f);
-                const float rstd = 1.0f / sqrtf(var + 1e-5f);
-                float* cp = C + (m0 + rl) * ldc + col_w;
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-                    cp[tn * 32] = (acc[tm][tn][e] - mean[tm][e]) * rstd * g[tn] + b[tn];
-            }
-        return;
-    }
-
-    float bias[4] = {0.f, 0.f, 0.f, 0.f};
-    if (EPI == SCREAM_EPI_BIAS_RELU) {
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) bias[tn] = ep.bias[col_w + tn * 32];
+        p0 = ld4(ep.gamma + col);
+        p1 = ld4(ep.beta + col);
     }
     const bool act = n0 < ep.n_act;  // n_act is a multiple of 256: uniform per block
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int g = 0; g < 4; ++g) {  // rows 8g .. 8g+7 of the wave's 32
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int rl = row_w + tm * 32 + mfma32_row(e, half);
-            float* cp = C + (m0 + rl) * ldc + col_w;
+        for (int tn = 0; tn < 8; ++tn)
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) {
-                float v = acc[tm][tn][e];
-                if (EPI == SCREAM_EPI_ELU1) {
-                    if (act) v = v > 0.f ? v + 1.0f : expm1f(v) + 1.0f;
-                } else if (EPI == SCREAM_EPI_RELU) {
-                    v = fmaxf(v, 0.f);
-                } else if (EPI == SCREAM_EPI_BIAS_RELU) {
-                    v = fmaxf(v + bias[tn], 0.f);
-                }
-                cp[tn * 32] = v;
+            for (int i = 0; i < 4; ++i) slab[(i + 4 * half) * SLAB_LD + tn * 32 + r] = acc[tn][4 * g + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ld4(slab + i * SLAB_LD + lane * 4);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int64_t row0 = m0 + wave * 32 + 8 * g;
+        if (EPI == SCREAM_EPI_RES_LN) {
+            f32x4 res[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) res[i] = ld4(ep.residual + (row0 + i) * ep.ldr + col);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] += res[i];
+                const float mean = wave_sum((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) * (1.0f / 256.0f);
+                const f32x4 d = v[i] - mean;
+                const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 256.0f);
+                const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                v[i] = d * rstd * p0 + p1;
             }
+        } else if (EPI == SCREAM_EPI_ELU1) {
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[i][c] = v[i][c] > 0.f ? v[i][c] + 1.0f : expf(v[i][c]);  // elu(x)+1 == exp(x) for x <= 0
+            }
+        } else if (EPI == SCREAM_EPI_RELU) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[i][c] = fmaxf(v[i][c], 0.f);
+        } else if (EPI == SCREAM_EPI_BIAS_RELU) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[i][c] = fmaxf(v[i][c] + p0[c], 0.f);
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(C + (row0 + i) * ldc + col) = v[i];
+    }
 }
 
 template <int EPI>
@@ -227,8 +224,9 @@ extern "C" int scream_gemm_f32(const float* A, int64_t lda, const float* W, floa
                                void* stream) {
     SCREAM_REQUIRE(A && W && C, SCREAM_EINVAL);
     SCREAM_REQUIRE(M >= 0 && M % BM == 0 && N > 0 && N % BN == 0 && K > 0 && K % BK == 0, SCREAM_EUNSUPPORTED);
-    SCREAM_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0, SCREAM_EINVAL);
-    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0 && ldc % 4 == 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(C) & 15) == 0, SCREAM_EINVAL);
     EpiArgs ep{n_act, bias, residual, ldr, gamma, beta};
     hipStream_t st = as_stream(stream);
     switch (epilogue) {
@@ -244,7 +242,8 @@ extern "C" int scream_gemm_f32(const float* A, int64_t lda, const float* W, floa
             return launch<SCREAM_EPI_BIAS_RELU>(A, lda, W, C, ldc, M, N, K, ep, st);
         case SCREAM_EPI_RES_LN:
             SCREAM_REQUIRE(N == BN, SCREAM_EUNSUPPORTED);
-            SCREAM_REQUIRE(residual && gamma && beta && ldr >= N, SCREAM_EINVAL);
+            SCREAM_REQUIRE(residual && gamma && beta && ldr >= N && ldr % 4 == 0, SCREAM_EINVAL);
+            SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(residual) & 15) == 0, SCREAM_EINVAL);
             return launch<SCREAM_EPI_RES_LN>(A, lda, W, C, ldc, M, N, K, ep, st);
         default:
             return SCREAM_EINVAL;
