@@ -92,8 +92,11 @@ def aggregate_rows(rows: np.ndarray, re_static_method: str = "median"):
 
 @torch.no_grad()
 def evaluate_items(net, items: Sequence[tuple], pair_ids: Sequence[int], corr: str = "tgt", dis_thresh: float = 0.1,
-                   icp: Optional[Callable] = None, device: Optional[torch.device] = None) -> np.ndarray:
-    """One batch: items are raw 9-tuples.  Returns metric rows [B, 8] (dist.ROW_WIDTH layout)."""
+                   icp: Optional[Callable] = None, device: Optional[torch.device] = None,
+                   pred_hook: Optional[Callable] = None) -> np.ndarray:
+    """One batch: items are raw 9-tuples.  Returns metric rows [B, 8] (dist.ROW_WIDTH layout).
+    pred_hook(batch, src_pred, pair_ids) -> src_pred may replace the network's prediction (used for the
+    "registered src + noise" throughput/metric variant of SURVEY.md section 8d and by the parity tests)."""
     device = device or next(net.parameters()).device
     its = [_strip(it) for it in items]
     srcs = [it[0].to(device) for it in its]
@@ -101,6 +104,8 @@ def evaluate_items(net, items: Sequence[tuple], pair_ids: Sequence[int], corr: s
     cents = [it[3].reshape(3).to(device) for it in its]  # src_center = trans^T, evaluate_3d_match.py:84
     batch = PackedBatch.from_pairs(srcs, tgts, cents)
     src_pred = net.forward_packed(batch)
+    if pred_hook is not None:
+        src_pred = pred_hook(batch, src_pred, pair_ids)
     s = torch.tensor([it[4] for it in its], dtype=torch.float32, device=device)
     c = torch.stack([it[7] for it in its]).to(device)
     T, n_corr, idx, dmin, valid = register_batch(batch, src_pred, s, c, dis_thresh, corr)
@@ -124,7 +129,7 @@ def evaluate_items(net, items: Sequence[tuple], pair_ids: Sequence[int], corr: s
 
 def evaluate_loader(net, loader: Iterable, corr: str = "tgt", dis_thresh: float = 0.1,
                     re_static_method: str = "median", batch_pairs: int = 32, icp: Optional[Callable] = None,
-                    verbose: bool = True):
+                    verbose: bool = True, pred_hook: Optional[Callable] = None):
     """evaluate_3d_match.py:53-171.  ``loader`` is a dataset or DataLoader of the reference's 9-tuples.
     With torch.distributed initialised the pairs are sharded round-robin over ranks and the per-pair rows
     are all-gathered once at the end; every rank returns the same (point_trans_loss, rre, rte, rr)."""
@@ -136,7 +141,7 @@ def evaluate_loader(net, loader: Iterable, corr: str = "tgt", dis_thresh: float 
     done = 0
     for b0 in range(0, len(mine), batch_pairs):
         ids = mine[b0:b0 + batch_pairs]
-        r = evaluate_items(net, [dataset[i] for i in ids], ids, corr, dis_thresh, icp)
+        r = evaluate_items(net, [dataset[i] for i in ids], ids, corr, dis_thresh, icp, pred_hook=pred_hook)
         rows.append(r)
         done += len(ids)
         if verbose and rank == 0:

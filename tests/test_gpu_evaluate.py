@@ -1,0 +1,86 @@
+"""evaluate_loader (evaluate_3d_match.py:53-171) on the MI355X against a per-pair oracle restatement of the
+same loop, on seeded synthetic 3DMatch-like pairs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import scream_ref as O
+from scream_amd import dist as sdist
+from scream_amd.data import SyntheticPairs
+from scream_amd.synthetic import make_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _noisy_registered(item, pair_id):
+    src, tgt, rot, trans, s = item[0], item[1], item[2], item[3], item[4]
+    rng = np.random.default_rng(1000 + pair_id)
+    return (rot @ src.T + trans).T + torch.from_numpy(rng.normal(scale=0.01 * s, size=src.shape).astype(np.float32))
+
+
+@pytest.mark.parametrize("kind,corr,method", [("3dmatch", "tgt", "median"), ("zero", "src_pred", "mean")])
+def test_evaluate_loader_rows_vs_oracle(kind, corr, method):
+    from scream_amd.evaluate import aggregate_rows, evaluate_items, evaluate_loader
+    from scream_amd.model import PointTransformer
+    assert torch.cuda.is_available()
+    net = PointTransformer(256, 1, 1)
+    sd = make_state_dict(2, 256, 1, 1)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    ds = SyntheticPairs(kind, 5, seed0=40)
+    items = [ds[i] for i in range(len(ds))]
+
+    def hook(batch, src_pred, ids):  # registered src + 1 cm noise so that the threshold keeps real correspondences
+        out = src_pred.clone()
+        for k, i in enumerate(ids):
+            r0 = int(batch.cloud_row0_host[k])
+            out[r0:r0 + items[i][0].shape[0]] = _noisy_registered(items[i], i).to(DEV)
+        return out
+
+    rows = evaluate_items(net, items, list(range(5)), corr, 0.1, None, pred_hook=hook)
+    want = np.zeros_like(rows)
+    for i, it in enumerate(items):
+        src, tgt, rot, trans, s, idx, cov, c, scene = it
+        pred = _noisy_registered(it, i)
+        d, nn_idx, valid = O.nn_search(pred[None], tgt[None], s, 0.1)
+        A, B = O.gather_correspondences(src[None], tgt[None], pred[None], nn_idx, valid, s, c, corr)
+        T = O.rigid_transform_3d(A, B)[0]
+        Tgt = O.gt_pose_metric(rot, trans, s, c)
+        re, te = O.transformation_error(T, Tgt)
+        rmse = math.sqrt(max(O.rmse_metric(np.linalg.inv(Tgt.numpy()) @ T.numpy(), cov.numpy()), 0.0))
+        loss = O.point_loss(pred[None], src[None], rot[None], trans[None]).item()
+        want[i] = [i, scene, float(abs(int(idx[1]) - int(idx[0])) > 1), float(rmse < 0.2), re.item(), te.item(), rmse, loss]
+    np.testing.assert_array_equal(rows[:, :4], want[:, :4])  # ids, scene, counted, success
+    np.testing.assert_allclose(rows[:, sdist.COL_RE], want[:, sdist.COL_RE], atol=0.05)   # acos conditioning near 0 deg
+    np.testing.assert_allclose(rows[:, sdist.COL_TE], want[:, sdist.COL_TE], atol=1e-4)
+    np.testing.assert_allclose(rows[:, sdist.COL_RMSE], want[:, sdist.COL_RMSE], atol=2e-4)
+    np.testing.assert_allclose(rows[:, sdist.COL_LOSS], want[:, sdist.COL_LOSS], rtol=1e-5)
+    if corr == "tgt":
+        assert rows[:, sdist.COL_SUCCESS].sum() >= 4  # a near-GT prediction registers
+    out = evaluate_loader(net, ds, corr=corr, dis_thresh=0.1, re_static_method=method, batch_pairs=2, verbose=False, pred_hook=hook)
+    np.testing.assert_allclose(out, aggregate_rows(rows, method), rtol=1e-6, atol=1e-9)  # batching does not change results
+
+
+def test_reference_call_signature_with_in_model_transform():
+    """models/pointnet.py:38-91 called exactly as evaluate_3d_match.py:83-87 does, plus get_transform=True."""
+    from models.pointnet import PointTransformer
+    import utils
+    net = PointTransformer(256, 1, 1)
+    sd = make_state_dict(4, 256, 1, 1)
+    net.load_state_dict(sd)
+    net.to(DEV).eval()
+    item = SyntheticPairs("3dmatch", 1, seed0=7)[0]
+    src, tgt, rot, trans, s = (item[0][None].to(DEV), item[1][None].to(DEV), item[2][None].to(DEV), item[3][None].to(DEV), item[4])
+    filt = (torch.matmul(rot, src.permute([0, 2, 1])) + trans).permute([0, 2, 1])
+    src_pred, imgs, transform = net(src, tgt, trans.permute([0, 2, 1]), s, False, True, filt)
+    assert src_pred.shape == src.shape and imgs is None and transform.shape == (4, 4)
+    want = O.point_transformer_forward(item[0][None], item[1][None], sd, item[3].reshape(1, 1, 3))
+    torch.testing.assert_close(src_pred.cpu(), want, rtol=2e-4, atol=5e-5)
+    d, idx, valid = O.nn_search(src_pred.cpu(), filt.cpu(), s, 0.075)
+    T = O.rigid_transform_3d(item[0][None][:, valid], filt.cpu()[:, idx[valid]])[0]
+    assert torch.linalg.norm(transform.cpu() - T).item() < 1e-4
+    re, te = utils.transformation_error(transform, transform)
+    assert re.dim() == 0 and te.item() == 0.0
