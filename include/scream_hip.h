@@ -51,7 +51,8 @@ int scream_abi_version(void);
 
 /* ---- A2/A4/A6: C[M,N] = epilogue(A[M,K] . W[N,K]^T), fp32-input MFMA (v_mfma_f32_32x32x2_f32).
  * Replaces torch.nn.Linear / Conv1d(k=1) at models/transformer.py:79-81,83,87 and
- * models/pointnet.py:60.  M % 128 == 0, N % 256 == 0, K % 32 == 0, lda/ldc/ldr in floats. */
+ * models/pointnet.py:60.  M % 128 == 0, N % 256 == 0, K % 64 == 0; lda/ldc/ldr in floats, multiples of 4;
+ * A, W, C and residual 16-byte aligned. */
 int scream_gemm_f32(const float* A, int64_t lda, const float* W, float* C, int64_t ldc,
                     int64_t M, int32_t N, int32_t K, int32_t epilogue, int32_t n_act,
                     const float* bias, const float* residual, int64_t ldr,

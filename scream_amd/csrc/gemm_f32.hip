@@ -7,23 +7,29 @@
 //
 // Geometry (MI355X_MICROARCH.md: 64 FLOP/clk/SIMD for f32 MFMA, 160 KiB LDS/CU):
 //   block tile 128 x 256, BK = 32, 256 threads = 4 waves stacked in M; wave tile 32 x 256
-//   = 8 MFMA tiles of 32x32 -> 128 accumulator registers; 2 blocks per CU (54 KiB LDS each)
-//   so the second block's MFMAs cover the first block's staging/barriers.
-//   Both operands are K-contiguous.  A k-chunk of 8 is split so that lane (r, half) holds
-//   k = 4*half .. 4*half+3 of row r for BOTH operands: the contraction index is a dummy, so any
-//   k permutation shared by A and W is legal, and it lets every fragment be one ds_read_b128.
-//   LDS rows are padded to 36 floats: the four 16-lane groups of a ds_read_b128 then hit 16
-//   distinct 4-bank slots (36 r mod 64 is a bijection on r mod 16) -> conflict free (measured:
-//   SQ_LDS_BANK_CONFLICT = 0, profiles/r01_v1_bench_pmc_mfma_lds.txt).
-//   Staging is global -> registers (issued before the MFMAs of the current tile) -> LDS
-//   (written after them); fp32 MFMA is slow enough (64 cycles each) that this is fully hidden.
+//   = 8 MFMA tiles of 32x32 -> 128 accumulator registers; 2 blocks per CU (64 KiB LDS each).
+//   The contraction index is a dummy, so any k permutation shared by A and W is legal: within a
+//   32-deep k-tile lane (r, half) owns k = 16*half + 4*j + i (j, i = 0..3) of row r for BOTH operands.
+//   * A (activations): every wave only ever needs its own 32 rows, so A never touches LDS.  Lane (r, half)
+//     loads its 64 contiguous bytes of row r per k-tile with four global_load_dwordx4 straight into
+//     registers (the two half-waves together consume each 128-byte line exactly once), one tile ahead.
+//   * W (weights, shared by the four waves): LDS-DMA (global_load_lds_dwordx4), double buffered, one tile
+//     ahead, no VGPRs and no ds_write pass.  The DMA writes LDS lane-linearly (8 rows of 128 B per wave
+//     instruction), so rows are unpadded and the bank-conflict fix is an XOR swizzle applied to the per-lane
+//     SOURCE address and to the read: 16-byte chunk c of row n lives at chunk c ^ ((n >> 1) & 7).  The 16
+//     lanes of a ds_read_b128 group then cover 16 distinct (n & 1, c') slots -> conflict free.
+//   * one barrier per k-tile (the DMA of tile t+1 lands under the MFMAs of tile t); fragment reads are
+//     software-pipelined half a k-chunk ahead of their MFMAs.
 //   Epilogue: a wave owns whole 256-wide rows, so LayerNorm statistics never leave the wave, and
 //   the accumulators go through a wave-private LDS slab (8 rows at a time) to turn the MFMA layout
 //   (lane = column) into row-major float4 per lane: every residual load and output store is one
-//   full 1 KiB row per wave instruction (v1 issued 128 dword stores per lane and lost ~25 % of the
-//   MFMA time to store issue).
-//   Blocks are renumbered so that the N-tiles of one M-tile run back to back on ONE XCD (shared A
-//   tile in that XCD's L2) -- placement only changes speed, never results.
+//   full 1 KiB row per wave instruction.
+//   Persistent blocks: the grid is at most 2 blocks per CU and every block walks its tiles (stride = grid),
+//   issuing the first k-tile of its NEXT output tile (DMA + A registers) before it starts the epilogue of
+//   the current one, so neither the workgroup dispatch gap (~5k cycles) nor the first-load latency (~10k
+//   cycles, s_memtime stamps in profiles/r01_gemm_stamps.txt) sits on the critical path any more.
+//   Tiles are numbered so that the N-tiles of one M-tile run back to back on ONE XCD (shared A
+//   rows in that XCD's L2) -- placement only changes speed, never results.
 #include "common.h"
 
 namespace {
@@ -31,8 +37,9 @@ namespace {
 constexpr int BM = 128;
 constexpr int BN = 256;
 constexpr int BK = 32;
-constexpr int LDS_LD = 36;  // floats per LDS row (32 + 4 pad)
+constexpr int WTILE = BN * BK;  // floats per W tile buffer (unpadded, swizzled)
 constexpr int THREADS = 256;
+constexpr int MAX_GRID = 512;   // 256 CUs x 2 resident blocks
 
 struct EpiArgs {
     int n_act;
@@ -45,162 +52,213 @@ struct EpiArgs {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 template <int EPI>
 __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                              const float* __restrict__ W,
                                                              float* __restrict__ C, int64_t ldc, int n_tiles,
-                                                             int K, EpiArgs ep) {
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
-    float* As = smem;
-    float* Bs = smem + BM * LDS_LD;
+                                                             unsigned total_tiles, int K, EpiArgs ep) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * WTILE];  // 64 KiB: two W tiles; buffer 1 doubles as epilogue slabs
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, half = lane >> 5;
 
-    // XCD-aware renumbering (bijective for any grid size): blocks b, b+8, b+16, ... share an XCD, give them
-    // consecutive tiles so the n_tiles blocks that read one A tile hit the same L2.
-    const unsigned nb = gridDim.x, bid = blockIdx.x;
-    const unsigned xcd = bid & 7u, q = nb >> 3, rem = nb & 7u;
-    const unsigned tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-    const int64_t mt = tile / n_tiles;
-    const int nt = tile % n_tiles;
-    const int64_t m0 = mt * BM;
-    const int n0 = nt * BN;
+    // Tile numbering (bijective for any tile count): virtual ids v, v+8, v+16, ... share an XCD (the grid is a
+    // multiple of 8 whenever a block owns more than one tile), give them consecutive tiles so the n_tiles
+    // tiles that read one block of A rows hit the same L2.
+    const unsigned q8 = total_tiles >> 3, rem = total_tiles & 7u;
+    auto tile_of = [&](unsigned v) {
+        const unsigned xcd = v & 7u;
+        return (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (v >> 3);
+    };
 
-    // staging map: float4 index f = tid + 256 i -> row f >> 3, 16-byte column f & 7
-    const int srow = tid >> 3, sc4 = tid & 7;
-    const float* ga = A + (m0 + srow) * lda + sc4 * 4;
-    const float* gw = W + (int64_t)(n0 + srow) * K + sc4 * 4;
-    const int lds_st = srow * LDS_LD + sc4 * 4;
+    // W DMA: wave-instruction q (0..7) of this wave fills LDS rows (wave*8+q)*8 .. +7 (1 KiB, lane-linear):
+    // lane -> row nq = (wave*8+q)*8 + (lane>>3), destination chunk c' = lane & 7, source chunk c = c' ^ ((nq>>1)&7)
+    // where (nq>>1)&7 = (4q + (lane>>4)) & 7, i.e. one value for even q and that value ^ 4 for odd q.
+    const int c_even = (lane & 7) ^ ((lane >> 4) & 7);
+    const int64_t w_qstride = (int64_t)8 * K;
+    // B fragment read: row n = tn*32 + r, chunk (half*4 + j) -> c' = (half*4 + j) ^ ((r >> 1) & 7)
+    const int sw = (r >> 1) & 7;
+    int boff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) boff[j] = r * BK + (((half * 4 + j) ^ sw) << 2);
 
-    f32x4 ra[4], rb[8];
+    auto dma_w = [&](const float* gw, int buf, int kt) {
+        const float* src = gw + (int64_t)kt * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = ld4(ga + (int64_t)(32 * i) * lda);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) rb[i] = ld4(gw + (int64_t)(32 * i) * K);
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int tn = 0; tn < 8; ++tn)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[tn][e] = 0.f;
-
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(As + lds_st + 32 * i * LDS_LD) = ra[i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(Bs + lds_st + 32 * i * LDS_LD) = rb[i];
-    __syncthreads();
-
-    const float* a_frag = As + (wave * 32 + r) * LDS_LD + half * 4;
-    const float* b_frag = Bs + r * LDS_LD + half * 4;
-    const int KT = K / BK;
-    for (int kt = 0; kt < KT; ++kt) {
-        const bool more = kt + 1 < KT;
-        if (more) {
-            ga += BK;
-            gw += BK;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = ld4(ga + (int64_t)(32 * i) * lda);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) rb[i] = ld4(gw + (int64_t)(32 * i) * K);
+        for (int q = 0; q < 8; ++q) {
+            const int c = (q & 1) ? (c_even ^ 4) : c_even;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + q * w_qstride + c * 4),
+                                             (lptr_t)(smem + buf * WTILE + (wave * 8 + q) * 256), 16, 0, 0);
         }
-        // 8 half-chunks (4 k-chunks x 2 halves of the 8 N-tiles), software pipelined: the LDS reads of
-        // half-chunk h+1 are issued BEFORE the 16 MFMAs of half-chunk h, into the other fragment set.
-        f32x4 fa[2], fb[2][4];
-        fa[0] = ld4(a_frag);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) fb[0][t] = ld4(b_frag + t * 32 * LDS_LD);
-#pragma unroll
-        for (int hc = 0; hc < 8; ++hc) {
-            const int cur = hc & 1, nxt = cur ^ 1;
-            if (hc + 1 < 8) {
-                const int kk = (hc + 1) >> 1, th = (hc + 1) & 1;
-                fa[nxt] = ld4(a_frag + kk * 8);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) fb[nxt][t] = ld4(b_frag + (th * 4 + t) * 32 * LDS_LD + kk * 8);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks these reads to just before their use
-            const int th0 = hc & 1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc[th0 * 4 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][j], fb[cur][t][j], acc[th0 * 4 + t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads above, the next half-chunk's below
-        }
-        __syncthreads();
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(As + lds_st + 32 * i * LDS_LD) = ra[i];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(Bs + lds_st + 32 * i * LDS_LD) = rb[i];
-            __syncthreads();
-        }
-    }
+    };
+    // A: lane (r, half) streams 64 contiguous bytes of its row per k-tile
+    auto a_ptr = [&](int64_t m0) { return A + (m0 + wave * 32 + r) * lda + half * 16; };
+    auto w_ptr = [&](int n0) { return W + (int64_t)(n0 + wave * 64 + (lane >> 3)) * K; };
 
-    // ------------------------------------------------------------------ epilogue (wave-private)
-    // acc[tn][e]: row = wave*32 + mfma32_row(e, half), col = tn*32 + r.  The loop above ended on a barrier, so
-    // the staging LDS is free: each wave takes its own slab and never synchronises with the others again.
-    constexpr int SLAB_LD = 260;  // 256 + 4 floats
-    float* slab = smem + wave * (8 * SLAB_LD);  // 8 rows; 4 x 8320 B <= 55296 B
-    const int col = n0 + lane * 4;
-    f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};  // bias | gamma, beta
-    if (EPI == SCREAM_EPI_BIAS_RELU) p0 = ld4(ep.bias + col);
-    if (EPI == SCREAM_EPI_RES_LN) {
-        p0 = ld4(ep.gamma + col);
-        p1 = ld4(ep.beta + col);
-    }
-    const bool act = n0 < ep.n_act;  // n_act is a multiple of 256: uniform per block
+    const int KT = K / BK;  // even (host check): every output tile starts on LDS buffer 0 / register set a0
+    unsigned v = blockIdx.x;
+    unsigned tile = tile_of(v);
+    int64_t m0 = (int64_t)(tile / n_tiles) * BM;
+    int n0 = (int)(tile % n_tiles) * BN;
+    const float* ga = a_ptr(m0);
+    const float* gw = w_ptr(n0);
+
+    f32x4 a0[4], a1[4];  // A fragments of the current / next k-tile (named, so indices stay static)
+    dma_w(gw, 0, 0);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {  // rows 8g .. 8g+7 of the wave's 32
+    for (int j = 0; j < 4; ++j) a0[j] = ld4(ga + j * 4);
+    __syncthreads();  // with an LDS-DMA in flight hipcc drains vmcnt(0) here: k-tile 0 has landed for every wave
+
+    for (;;) {
+        f32x16 acc[8];
 #pragma unroll
         for (int tn = 0; tn < 8; ++tn)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) slab[(i + 4 * half) * SLAB_LD + tn * 32 + r] = acc[tn][4 * g + i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        f32x4 v[8];
+            for (int e = 0; e < 16; ++e) acc[tn][e] = 0.f;
+
+        // one k-tile: prefetch k-tile kt+1 (DMA + A registers), 128 MFMAs on k-tile kt, barrier
+        auto step = [&](int kt, int buf, f32x4 (&ac)[4], f32x4 (&an)[4]) {
+            // Retire the loads of this tile's A registers HERE, while nothing younger is in flight (they were
+            // issued a whole tile ago and the barrier already drained them): with an LDS-DMA outstanding hipcc
+            // would otherwise put s_waitcnt vmcnt(0) in front of the first MFMA and serialise tile t+1's
+            // transfer with tile t's math.
+            asm volatile("" : "+v"(ac[0]), "+v"(ac[1]), "+v"(ac[2]), "+v"(ac[3]));
+            if (kt + 1 < KT) {
+                dma_w(gw, buf ^ 1, kt + 1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = ld4(slab + i * SLAB_LD + lane * 4);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int64_t row0 = m0 + wave * 32 + 8 * g;
-        if (EPI == SCREAM_EPI_RES_LN) {
-            f32x4 res[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) res[i] = ld4(ep.residual + (row0 + i) * ep.ldr + col);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                v[i] += res[i];
-                const float mean = wave_sum((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) * (1.0f / 256.0f);
-                const f32x4 d = v[i] - mean;
-                const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 256.0f);
-                const float rstd = 1.0f / sqrtf(var + 1e-5f);
-                v[i] = d * rstd * p0 + p1;
+                for (int j = 0; j < 4; ++j) an[j] = ld4(ga + (kt + 1) * BK + j * 4);
             }
-        } else if (EPI == SCREAM_EPI_ELU1) {
-            if (act) {
+            const float* wb = smem + buf * WTILE;
+            f32x4 fb[2][4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+            for (int t = 0; t < 4; ++t) fb[0][t] = ld4(wb + t * 32 * BK + boff[0]);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[i][c] = v[i][c] > 0.f ? v[i][c] + 1.0f : expf(v[i][c]);  // elu(x)+1 == exp(x) for x <= 0
+            for (int hc = 0; hc < 8; ++hc) {  // half-chunk hc: j = hc >> 1, N-tiles (hc & 1)*4 .. +3
+                const int cur = hc & 1, nxt = cur ^ 1;
+                if (hc + 1 < 8) {
+                    const int j2 = (hc + 1) >> 1, th2 = (hc + 1) & 1;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) fb[nxt][t] = ld4(wb + (th2 * 4 + t) * 32 * BK + boff[j2]);
+                }
+                const int j = hc >> 1, th = hc & 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[th * 4 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[j][i], fb[cur][t][i], acc[th * 4 + t], 0, 0, 0);
+                // Pin the order inside this half-chunk: first MFMA (its lgkmcnt wait then only covers reads issued a
+                // half-chunk ago), then the 4 prefetch reads, then the other 15 MFMAs.  With an LDS-DMA in flight hipcc
+                // emits lgkmcnt(0) rather than a counted wait, so the prefetch must sit BEHIND that first MFMA.
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        } else if (EPI == SCREAM_EPI_RELU) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[i][c] = fmaxf(v[i][c], 0.f);
-        } else if (EPI == SCREAM_EPI_BIAS_RELU) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[i][c] = fmaxf(v[i][c] + p0[c], 0.f);
+            __syncthreads();  // all reads of `buf` done; k-tile kt+1 landed (vmcnt(0) drained by the barrier's fence)
+        };
+        for (int kt = 0; kt < KT; kt += 2) {
+            step(kt, 0, a0, a1);
+            step(kt + 1, 1, a1, a0);
         }
+
+        // ---- next output tile: start its first k-tile now so that it lands under the epilogue ----------------
+        const unsigned v_next = v + gridDim.x;
+        const bool has_next = v_next < total_tiles;
+        const int64_t m0_cur = m0;
+        const int n0_cur = n0;
+        if (has_next) {
+            tile = tile_of(v_next);
+            m0 = (int64_t)(tile / n_tiles) * BM;
+            n0 = (int)(tile % n_tiles) * BN;
+            ga = a_ptr(m0);
+            gw = w_ptr(n0);
+        }
+        // RES_LN's residual loads would be waited for with vmcnt(0) behind the DMA (hipcc, LDS-DMA in flight), so that
+        // epilogue prefetches afterwards; the others have no loads and take the prefetch first.
+        if (EPI != SCREAM_EPI_RES_LN && has_next) {
+            dma_w(gw, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(C + (row0 + i) * ldc + col) = v[i];
+            for (int j = 0; j < 4; ++j) a0[j] = ld4(ga + j * 4);
+        }
+
+        // ---- epilogue (wave-private) ---------------------------------------------------------------------------
+        // acc[tn][e]: row = wave*32 + mfma32_row(e, half), col = tn*32 + r.  The k-loop ended on a barrier and its
+        // last k-tile used buffer 0's partner, so buffer 1 is free: each wave takes an 8-row slab of it.
+        constexpr int SLAB_LD = 256;
+        float* slab = smem + WTILE + wave * (8 * SLAB_LD);
+        const int col = n0_cur + lane * 4;
+        f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};  // bias | gamma, beta
+        if (EPI == SCREAM_EPI_BIAS_RELU) p0 = ld4(ep.bias + col);
+        if (EPI == SCREAM_EPI_RES_LN) {
+            p0 = ld4(ep.gamma + col);
+            p1 = ld4(ep.beta + col);
+        }
+        const bool act = n0_cur < ep.n_act;  // n_act is a multiple of 256: uniform per tile
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // rows 8g .. 8g+7 of the wave's 32
+#pragma unroll
+            for (int tn = 0; tn < 8; ++tn)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) slab[(i + 4 * half) * SLAB_LD + tn * 32 + r] = acc[tn][4 * g + i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {  // two halves of 4 rows: keeps the live set inside 256 VGPRs
+                f32x4 vv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vv[i] = ld4(slab + (hh * 4 + i) * SLAB_LD + lane * 4);
+                const int64_t row0 = m0_cur + wave * 32 + 8 * g + 4 * hh;
+                if (EPI == SCREAM_EPI_RES_LN) {
+                    f32x4 res[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) res[i] = ld4(ep.residual + (row0 + i) * ep.ldr + col);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        vv[i] += res[i];
+                        const float mean = wave_sum((vv[i][0] + vv[i][1]) + (vv[i][2] + vv[i][3])) * (1.0f / 256.0f);
+                        const f32x4 d = vv[i] - mean;
+                        const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 256.0f);
+                        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                        vv[i] = d * rstd * p0 + p1;
+                    }
+                } else if (EPI == SCREAM_EPI_ELU1) {
+                    if (act) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) vv[i][c] = vv[i][c] > 0.f ? vv[i][c] + 1.0f : expf(vv[i][c]);  // elu(x)+1 == exp(x), x <= 0
+                    }
+                } else if (EPI == SCREAM_EPI_RELU) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) vv[i][c] = fmaxf(vv[i][c], 0.f);
+                } else if (EPI == SCREAM_EPI_BIAS_RELU) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) vv[i][c] = fmaxf(vv[i][c] + p0[c], 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(C + (row0 + i) * ldc + col) = vv[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!has_next) break;
+        v = v_next;
+        if (EPI == SCREAM_EPI_RES_LN) {
+            dma_w(gw, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a0[j] = ld4(ga + j * 4);
+        }
+        __syncthreads();  // next tile's k-tile 0 landed (vmcnt(0)); every wave is done with its slab
     }
 }
 
@@ -208,10 +266,11 @@ template <int EPI>
 int launch(const float* A, int64_t lda, const float* W, float* C, int64_t ldc, int64_t M, int N, int K,
            const EpiArgs& ep, hipStream_t st) {
     const int n_tiles = N / BN;
-    const int64_t blocks = (M / BM) * n_tiles;
-    if (blocks == 0) return 0;
-    SCREAM_REQUIRE(blocks < (1ll << 31), SCREAM_EUNSUPPORTED);
-    gemm_f32_kernel<EPI><<<dim3((unsigned)blocks), dim3(THREADS), 0, st>>>(A, lda, W, C, ldc, n_tiles, K, ep);
+    const int64_t total = (M / BM) * n_tiles;
+    if (total == 0) return 0;
+    SCREAM_REQUIRE(total < (1ll << 31), SCREAM_EUNSUPPORTED);
+    const unsigned grid = total < MAX_GRID ? (unsigned)total : (unsigned)MAX_GRID;
+    gemm_f32_kernel<EPI><<<dim3(grid), dim3(THREADS), 0, st>>>(A, lda, W, C, ldc, n_tiles, (unsigned)total, K, ep);
     SCREAM_LAUNCH_CHECK();
     return 0;
 }
@@ -223,7 +282,7 @@ extern "C" int scream_gemm_f32(const float* A, int64_t lda, const float* W, floa
                                const float* residual, int64_t ldr, const float* gamma, const float* beta,
                                void* stream) {
     SCREAM_REQUIRE(A && W && C, SCREAM_EINVAL);
-    SCREAM_REQUIRE(M >= 0 && M % BM == 0 && N > 0 && N % BN == 0 && K > 0 && K % BK == 0, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE(M >= 0 && M % BM == 0 && N > 0 && N % BN == 0 && K > 0 && K % (2 * BK) == 0, SCREAM_EUNSUPPORTED);
     SCREAM_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0 && ldc % 4 == 0, SCREAM_EINVAL);
     SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(C) & 15) == 0, SCREAM_EINVAL);

@@ -31,7 +31,7 @@ def build_net(seed, n_self, n_cross):
 
 
 # ------------------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("M,N,K", [(128, 256, 256), (384, 768, 256), (256, 1024, 256), (256, 256, 1024), (128, 512, 32)])
+@pytest.mark.parametrize("M,N,K", [(128, 256, 256), (384, 768, 256), (256, 1024, 256), (256, 256, 1024), (128, 512, 64), (66048, 256, 256)])
 def test_gemm_plain_and_activations(M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)
