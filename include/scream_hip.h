@@ -189,6 +189,23 @@ int scream_rigid_transform_3d(const float* A, const float* B, const float* w,
 int scream_transformation_error(const float* T_pred, const float* T_gt, int32_t n, float* re,
                                 float* te, void* stream);
 
+/* ---- next row: batched point-to-point ICP refinement on the GPU.
+ * Replaces o3d.registration_icp(src_pc, tgt_pc, max_correspondence_distance, init) at
+ * evaluate_3d_match.py:106-113 / evaluate_kitti.py:61-70 (open3d is absent here: parity with open3d is
+ * unpinned; the loop is open3d's published RegistrationICP and is checked against oracle/icp_ref.py).
+ * src/ref packed, normalised frame; metric points are x / s + c.  T [n_pairs,16] holds the initial
+ * transforms on entry and the refined ones on return.  Per iteration: transform the source, thresholded
+ * 1-NN (distance <= max_corr_dist), fitness = #corr / N and inlier_rmse = sqrt(mean d^2); stop a pair when
+ * both change by less than rel_fitness / rel_rmse or after max_iter updates; otherwise compose the Kabsch
+ * update of the correspondences.  fitness_rmse [n_pairs,2] and iters [n_pairs] may be NULL. */
+int64_t scream_icp_workspace_bytes(int64_t src_rows_total, int64_t ref_rows_total, int32_t n_pairs);
+int scream_icp_p2p(const float* src, const float* ref, const int32_t* src_row0, const int32_t* src_len,
+                   const int32_t* ref_row0, const int32_t* ref_len, const float* s, const float* c,
+                   int32_t n_pairs, int32_t max_src_len, int32_t max_ref_len, int64_t src_rows_total,
+                   int64_t ref_rows_total, float max_corr_dist, int32_t max_iter, float rel_fitness,
+                   float rel_rmse, float* T, float* fitness_rmse, int32_t* iters, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,8 @@ SIGNATURES = {
     "scream_kabsch_corr": (C.c_int, [V, V, V, V, V, V, V, V, V, I32, V, V, V]),
     "scream_rigid_transform_3d": (C.c_int, [V, V, V, F32, I32, I32, V, V]),
     "scream_transformation_error": (C.c_int, [V, V, I32, V, V, V]),
+    "scream_icp_workspace_bytes": (C.c_int64, [I64, I64, I32]),
+    "scream_icp_p2p": (C.c_int, [V, V, V, V, V, V, V, V, I32, I32, I32, I64, I64, F32, I32, F32, F32, V, V, V, V, I64, V]),
 }
 
 _lib: Optional[C.CDLL] = None

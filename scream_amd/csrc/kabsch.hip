@@ -312,6 +312,110 @@ __global__ __launch_bounds__(64) void transformation_error_kernel(const float* _
     te[i] = sqrtf((dx * dx + dy * dy) + dz * dz);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Point-to-point ICP refinement (the "next" row of SURVEY.md 8f: evaluate_3d_match.py:106-119 calls
+// open3d.registration_icp, which is not in this image -> parity with open3d itself is UNPINNED; the loop
+// below follows open3d's published RegistrationICP: evaluate correspondences of the transformed source
+// (nearest target within max_dist), estimate the rigid update from them (Kabsch, no scaling),
+// compose, re-evaluate, stop when |d fitness| and |d inlier_rmse| both fall below their thresholds
+// or after max_iter updates).  It is exactly loop{ A7 with a radius, A8, A9 } in metric space, so it reuses
+// the search and solve kernels; all pairs of a batch iterate together and converged pairs freeze on the
+// device (no host synchronisation inside the loop).
+
+// metric frame: x / s + c (evaluate_3d_match.py:106-107)
+__global__ __launch_bounds__(256) void icp_to_metric_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ row0,
+                                                           const int32_t* __restrict__ len, const float* __restrict__ s,
+                                                           const float* __restrict__ c, float* __restrict__ out) {
+    const int p = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= len[p]) return;
+    const int64_t row = (int64_t)row0[p] + i;
+    out[row * 3 + 0] = xyz[row * 3 + 0] / s[p] + c[p * 3 + 0];
+    out[row * 3 + 1] = xyz[row * 3 + 1] / s[p] + c[p * 3 + 1];
+    out[row * 3 + 2] = xyz[row * 3 + 2] / s[p] + c[p * 3 + 2];
+}
+
+// q = R x + t with the pair's current transform
+__global__ __launch_bounds__(256) void icp_transform_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ row0,
+                                                           const int32_t* __restrict__ len, const float* __restrict__ T,
+                                                           float* __restrict__ out) {
+    const int p = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= len[p]) return;
+    const int64_t row = (int64_t)row0[p] + i;
+    const float* t = T + p * 16;
+    const float x = xyz[row * 3 + 0], y = xyz[row * 3 + 1], z = xyz[row * 3 + 2];
+    out[row * 3 + 0] = t[0] * x + t[1] * y + t[2] * z + t[3];
+    out[row * 3 + 1] = t[4] * x + t[5] * y + t[6] * z + t[7];
+    out[row * 3 + 2] = t[8] * x + t[9] * y + t[10] * z + t[11];
+}
+
+__global__ __launch_bounds__(256) void fill_f32_kernel(float* __restrict__ p, float v, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+struct IcpState {  // per pair
+    float fitness, rmse;
+    int32_t done, iters;
+};
+
+// One workgroup per pair: fitness / inlier RMSE of the current correspondences, convergence test, and (if the
+// pair goes on) the Kabsch update composed into T.  q = transformed source, idx/valid/dmin from the search.
+__global__ __launch_bounds__(256) void icp_update_kernel(const float* __restrict__ q, const float* __restrict__ ref,
+                                                        const int32_t* __restrict__ src_row0,
+                                                        const int32_t* __restrict__ src_len,
+                                                        const int32_t* __restrict__ ref_row0,
+                                                        const int32_t* __restrict__ idx,
+                                                        const uint8_t* __restrict__ valid,
+                                                        const float* __restrict__ dmin, int iter, int max_iter,
+                                                        float rel_fitness, float rel_rmse, float* __restrict__ T,
+                                                        IcpState* __restrict__ state, float* __restrict__ fit_rmse_out,
+                                                        int32_t* __restrict__ iters_out) {
+    __shared__ double red2[4 * 2];
+    const int p = blockIdx.x;
+    IcpState st = state[p];
+    if (st.done) return;  // block-uniform
+    const int n = src_len[p];
+    const int64_t r0 = src_row0[p];
+    double acc[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < n; i += 256)
+        if (valid[r0 + i]) {
+            acc[0] += 1.0;
+            acc[1] += (double)dmin[r0 + i];
+        }
+    block_sum<2>(acc, red2);
+    const float fitness = n > 0 ? (float)(acc[0] / n) : 0.f;
+    const float rmse = acc[0] > 0 ? (float)sqrt(acc[1] / acc[0]) : 0.f;
+    const bool converged = iter > 0 && fabsf(st.fitness - fitness) < rel_fitness && fabsf(st.rmse - rmse) < rel_rmse;
+    const bool stop = converged || iter >= max_iter;
+    __syncthreads();  // everyone has read state[p] before thread 0 rewrites it
+    if (threadIdx.x == 0) {
+        IcpState o = {fitness, rmse, stop ? 1 : 0, iter};
+        state[p] = o;
+        if (fit_rmse_out) {
+            fit_rmse_out[2 * p + 0] = fitness;
+            fit_rmse_out[2 * p + 1] = rmse;
+        }
+        if (iters_out) iters_out[p] = iter;  // number of updates applied
+    }
+    if (stop) return;
+    float dT[16];
+    CorrFetch f{q, ref, idx, valid, r0, ref_row0[p], 1.0f, 0.f, 0.f, 0.f, n};
+    __shared__ float dT_sh[16];
+    kabsch_block(f, dT_sh, nullptr);
+    __syncthreads();
+    if (threadIdx.x < 16) {  // T <- dT . T
+        const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v += dT_sh[i * 4 + k] * T[p * 16 + k * 4 + j];
+        dT[0] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) T[p * 16 + threadIdx.x] = dT[0];
+}
+
 }  // namespace
 
 extern "C" int scream_kabsch_corr(const float* src, const float* ref, const int32_t* src_row0, const int32_t* src_len,
@@ -342,5 +446,60 @@ extern "C" int scream_transformation_error(const float* T_pred, const float* T_g
     if (n == 0) return 0;
     transformation_error_kernel<<<dim3((n + 63) / 64), dim3(64), 0, as_stream(stream)>>>(T_pred, T_gt, n, re, te);
     SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t scream_icp_workspace_bytes(int64_t src_rows_total, int64_t ref_rows_total, int32_t n_pairs) {
+    if (src_rows_total < 0 || ref_rows_total < 0 || n_pairs < 0) return SCREAM_EINVAL;
+    // src metric + transformed src (3 floats each), ref metric (3) + nn ref_prep (4), keys (2), idx, dmin, valid, ones, state
+    return (src_rows_total * (3 + 3 + 2 + 1 + 1 + 1) + ref_rows_total * (3 + 4) + (int64_t)n_pairs * 8) * 4 + 4096;
+}
+
+extern "C" int scream_icp_p2p(const float* src, const float* ref, const int32_t* src_row0, const int32_t* src_len,
+                              const int32_t* ref_row0, const int32_t* ref_len, const float* s, const float* c,
+                              int32_t n_pairs, int32_t max_src_len, int32_t max_ref_len, int64_t src_rows_total,
+                              int64_t ref_rows_total, float max_corr_dist, int32_t max_iter, float rel_fitness,
+                              float rel_rmse, float* T, float* fitness_rmse, int32_t* iters, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+    SCREAM_REQUIRE(src && ref && src_row0 && src_len && ref_row0 && ref_len && s && c && T && workspace, SCREAM_EINVAL);
+    SCREAM_REQUIRE(n_pairs >= 0 && max_iter >= 0 && max_corr_dist > 0.f, SCREAM_EINVAL);
+    SCREAM_REQUIRE(workspace_bytes >= scream_icp_workspace_bytes(src_rows_total, ref_rows_total, n_pairs), SCREAM_EINVAL);
+    if (n_pairs == 0) return 0;
+    hipStream_t st = as_stream(stream);
+    float* w = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    auto take = [&](int64_t n) { float* r = w; w += (n + 63) / 64 * 64; return r; };
+    float* src_m = take(src_rows_total * 3);
+    float* q = take(src_rows_total * 3);
+    float* ref_m = take(ref_rows_total * 3);
+    float* ref_prep = take(ref_rows_total * 4);
+    uint64_t* keys = reinterpret_cast<uint64_t*>(take(src_rows_total * 2));
+    int32_t* idx = reinterpret_cast<int32_t*>(take(src_rows_total));
+    float* dmin = take(src_rows_total);
+    uint8_t* valid = reinterpret_cast<uint8_t*>(take((src_rows_total + 3) / 4));
+    float* ones = take(n_pairs);
+    IcpState* state = reinterpret_cast<IcpState*>(take((int64_t)n_pairs * 4));
+    SCREAM_REQUIRE(reinterpret_cast<char*>(w) <= reinterpret_cast<char*>(workspace) + workspace_bytes, SCREAM_EINVAL);
+
+    hipError_t e = hipMemsetAsync(state, 0, sizeof(IcpState) * n_pairs, st);
+    if (e != hipSuccess) return (int)e;
+    // ones[p] = 1.0f: the search's "scale" (it divides by it), since these clouds are already metric
+    fill_f32_kernel<<<dim3((n_pairs + 255) / 256), dim3(256), 0, st>>>(ones, 1.0f, n_pairs);
+    if (max_src_len > 0)
+        icp_to_metric_kernel<<<dim3((max_src_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(src, src_row0, src_len, s, c, src_m);
+    if (max_ref_len > 0)
+        icp_to_metric_kernel<<<dim3((max_ref_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(ref, ref_row0, ref_len, s, c, ref_m);
+    SCREAM_LAUNCH_CHECK();
+    for (int it = 0; it <= max_iter; ++it) {
+        if (max_src_len > 0)
+            icp_transform_kernel<<<dim3((max_src_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(src_m, src_row0, src_len, T, q);
+        SCREAM_LAUNCH_CHECK();
+        int rc = scream_nn_search(q, ref_m, src_row0, src_len, ref_row0, ref_len, ones, n_pairs, max_src_len, max_ref_len,
+                                  src_rows_total, ref_rows_total, max_corr_dist * max_corr_dist, ref_prep, keys, idx, dmin,
+                                  valid, stream);
+        if (rc != 0) return rc;
+        icp_update_kernel<<<dim3(n_pairs), dim3(256), 0, st>>>(q, ref_m, src_row0, src_len, ref_row0, idx, valid, dmin, it,
+                                                               max_iter, rel_fitness, rel_rmse, T, state, fitness_rmse, iters);
+        SCREAM_LAUNCH_CHECK();
+    }
     return 0;
 }

@@ -137,3 +137,22 @@ def transformation_error_batched(T_pred: torch.Tensor, T_gt: torch.Tensor) -> Tu
     check(_lib.load().scream_transformation_error(_p(T_pred), _p(T_gt), n, _p(re), _p(te), _stream()),
           "scream_transformation_error")
     return re, te
+
+
+def icp_p2p(src, ref, src_row0, src_len, ref_row0, ref_len, s, c, T_init, max_src_len: int, max_ref_len: int,
+            max_corr_dist: float, max_iter: int = 30, rel_fitness: float = 1e-6, rel_rmse: float = 1e-6):
+    """Batched point-to-point ICP (scream_icp_p2p).  Returns (T [n,4,4], fitness_rmse [n,2], iters int32 [n])."""
+    lib = _lib.load()
+    n_pairs = s.shape[0]
+    dev = src.device
+    T = T_init.detach().clone().contiguous().float()
+    fr = torch.empty(n_pairs, 2, device=dev, dtype=torch.float32)
+    iters = torch.empty(n_pairs, device=dev, dtype=torch.int32)
+    need = lib.scream_icp_workspace_bytes(src.shape[0], ref.shape[0], n_pairs)
+    ws = torch.empty(need, device=dev, dtype=torch.uint8)
+    check(lib.scream_icp_p2p(_p(src), _p(ref), _p(src_row0, torch.int32), _p(src_len, torch.int32),
+                             _p(ref_row0, torch.int32), _p(ref_len, torch.int32), _p(s), _p(c), n_pairs, max_src_len,
+                             max_ref_len, src.shape[0], ref.shape[0], float(max_corr_dist), int(max_iter),
+                             float(rel_fitness), float(rel_rmse), _p(T), _p(fr), _p(iters, torch.int32),
+                             ws.data_ptr(), need, _stream()), "scream_icp_p2p")
+    return T, fr, iters

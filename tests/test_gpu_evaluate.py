@@ -84,3 +84,65 @@ def test_reference_call_signature_with_in_model_transform():
     assert torch.linalg.norm(transform.cpu() - T).item() < 1e-4
     re, te = utils.transformation_error(transform, transform)
     assert re.dim() == 0 and te.item() == 0.0
+
+
+def test_gpu_icp_vs_oracle_loop():
+    """scream_icp_p2p against oracle/icp_ref.py (open3d's RegistrationICP loop restated on the CPU) for a packed
+    batch of two pairs started from perturbed ground-truth poses."""
+    from oracle.icp_ref import icp_p2p as icp_ref
+    from scream_amd import ops
+    from scream_amd.packing import PackedBatch
+    items = [SyntheticPairs("3dmatch", 2, seed0=60)[i] for i in range(2)]
+    srcs, tgts = [it[0].to(DEV) for it in items], [it[1].to(DEV) for it in items]
+    batch = PackedBatch.from_pairs(srcs, tgts, None)
+    s = torch.tensor([it[4] for it in items], dtype=torch.float32, device=DEV)
+    c = torch.stack([it[7] for it in items]).to(DEV)
+    rng = np.random.default_rng(0)
+    T0 = []
+    for it in items:
+        Tgt = O.gt_pose_metric(it[2], it[3], it[4], it[7]).double().numpy()
+        ang = np.radians(2.0)
+        Rz = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+        P = np.eye(4)
+        P[:3, :3] = Rz
+        P[:3, 3] = rng.normal(scale=0.02, size=3)
+        T0.append(P @ Tgt)
+    T0 = np.stack(T0)
+    tgt_row0 = (batch.tgt_row0 - batch.rows_src).contiguous()
+    T, fr, iters = ops.icp_p2p(batch.xyz[: batch.rows_src], batch.xyz[batch.rows_src:], batch.src_row0, batch.src_len_dev,
+                               tgt_row0, batch.tgt_len_dev, s, c, torch.from_numpy(T0).float().to(DEV),
+                               max(batch.src_len), max(batch.tgt_len), 0.1, 30)
+    T, fr, iters = T.cpu().numpy(), fr.cpu().numpy(), iters.cpu().numpy()
+    for i, it in enumerate(items):
+        src_m = (it[0] / it[4] + it[7]).double().numpy()
+        tgt_m = (it[1] / it[4] + it[7]).double().numpy()
+        Tr, fit, rmse, n_it = icp_ref(src_m, tgt_m, T0[i], 0.1, 30)
+        Tgt = O.gt_pose_metric(it[2], it[3], it[4], it[7]).double().numpy()
+        # both converge to the same fixed point, and that point is closer to the ground truth than the start
+        assert np.linalg.norm(T[i] - Tr) < 2e-3, (T[i], Tr)
+        assert abs(fr[i, 0] - fit) < 5e-3 and abs(fr[i, 1] - rmse) < 1e-3
+        assert np.linalg.norm(T[i] - Tgt) < 0.5 * np.linalg.norm(T0[i] - Tgt)
+        assert 1 <= iters[i] <= 30 and abs(int(iters[i]) - n_it) <= 3
+
+
+def test_evaluate_loader_with_gpu_icp_only_improves():
+    from scream_amd.evaluate import evaluate_items
+    from scream_amd.model import PointTransformer
+    net = PointTransformer(256, 1, 1)
+    net.load_state_dict(make_state_dict(2, 256, 1, 1))
+    net = net.to(DEV).eval()
+    ds = SyntheticPairs("3dmatch", 3, seed0=40)
+    items = [ds[i] for i in range(3)]
+
+    def hook(batch, src_pred, ids):
+        out = src_pred.clone()
+        for k, i in enumerate(ids):
+            r0 = int(batch.cloud_row0_host[k])
+            out[r0:r0 + items[i][0].shape[0]] = _noisy_registered(items[i], i).to(DEV)
+        return out
+
+    base = evaluate_items(net, items, [0, 1, 2], "tgt", 0.1, None, pred_hook=hook)
+    ref = evaluate_items(net, items, [0, 1, 2], "tgt", 0.1, "gpu", pred_hook=hook)
+    assert (ref[:, sdist.COL_RE] <= base[:, sdist.COL_RE] + 1e-6).all()
+    assert (ref[:, sdist.COL_TE] <= base[:, sdist.COL_TE] + 1e-9).all()
+    assert (ref[:, sdist.COL_TE] < base[:, sdist.COL_TE]).any()  # the accept rule fires on at least one pair
