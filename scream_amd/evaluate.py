@@ -97,26 +97,26 @@ def aggregate_rows(rows: np.ndarray, re_static_method: str = "median"):
 
 
 @torch.no_grad()
-def evaluate_items(net, items: Sequence[tuple], pair_ids: Sequence[int], corr: str = "tgt", dis_thresh: float = 0.1,
-                   icp: Optional[Callable] = None, device: Optional[torch.device] = None,
-                   pred_hook: Optional[Callable] = None) -> np.ndarray:
-    """One batch: items are raw 9-tuples.  Returns metric rows [B, 8] (dist.ROW_WIDTH layout).
-    pred_hook(batch, src_pred, pair_ids) -> src_pred may replace the network's prediction (used for the
-    "registered src + noise" throughput/metric variant of SURVEY.md section 8d and by the parity tests)."""
+def register_items(net, its: Sequence[tuple], centers: Sequence[torch.Tensor], pair_ids: Sequence[int],
+                   corr: str = "tgt", dis_thresh: float = 0.1, icp=None, icp_dist: float = ICP_MAX_CORR_DIST,
+                   icp_iters: int = ICP_MAX_ITER, device: Optional[torch.device] = None,
+                   pred_hook: Optional[Callable] = None):
+    """A1-A10 (+ optional ICP) for one batch.  its[i] = (src, tgt, rot, trans, s, c) normalised fp32 CPU tensors;
+    centers[i] = the src_center the evaluator passes to the model.  Returns host arrays
+    (T [B,4,4], T_gt [B,4,4], re [B], te [B], loss [B])."""
     device = device or next(net.parameters()).device
-    its = [_strip(it) for it in items]
     srcs = [it[0].to(device) for it in its]
     tgts = [it[1].to(device) for it in its]
-    cents = [it[3].reshape(3).to(device) for it in its]  # src_center = trans^T, evaluate_3d_match.py:84
-    batch = PackedBatch.from_pairs(srcs, tgts, cents)
+    batch = PackedBatch.from_pairs(srcs, tgts, [cc.reshape(3).to(device) for cc in centers])
     src_pred = net.forward_packed(batch)
     if pred_hook is not None:
         src_pred = pred_hook(batch, src_pred, pair_ids)
     s = torch.tensor([it[4] for it in its], dtype=torch.float32, device=device)
-    c = torch.stack([it[7] for it in its]).to(device)
+    c = torch.stack([it[5] for it in its]).to(device)
     T, n_corr, idx, dmin, valid = register_batch(batch, src_pred, s, c, dis_thresh, corr)
-    T_gt = torch.stack([gt_pose_metric(it[2], it[3], it[4], it[7]) for it in its])
-    re, te = ops.transformation_error_batched(T, T_gt.to(device))
+    T_gt = torch.stack([gt_pose_metric(it[2], it[3], it[4], it[5]) for it in its])
+    T_gt_d = T_gt.to(device)
+    re, te = ops.transformation_error_batched(T, T_gt_d)
     if isinstance(icp, str):
         if icp != "gpu":
             raise ValueError("icp must be None, 'gpu' or a callable")
@@ -125,30 +125,43 @@ def evaluate_items(net, items: Sequence[tuple], pair_ids: Sequence[int], corr: s
         tgt_row0 = (batch.tgt_row0 - batch.rows_src).contiguous()
         T2, _, _ = ops.icp_p2p(batch.xyz[: batch.rows_src], batch.xyz[batch.rows_src:], batch.src_row0,
                                batch.src_len_dev, tgt_row0, batch.tgt_len_dev, s, c, T, max(batch.src_len),
-                               max(batch.tgt_len), ICP_MAX_CORR_DIST, ICP_MAX_ITER)
-        re2, te2 = ops.transformation_error_batched(T2, T_gt.to(device))
+                               max(batch.tgt_len), icp_dist, icp_iters)
+        re2, te2 = ops.transformation_error_batched(T2, T_gt_d)
         better = (re2 <= re) & (te2 <= te)
         T = torch.where(better[:, None, None], T2, T)
         re, te = torch.where(better, re2, re), torch.where(better, te2, te)
-        icp = None
-    T_h, re_h, te_h = T.cpu().numpy(), re.cpu().numpy(), te.cpu().numpy()
+    T_h, re_h, te_h = T.cpu().numpy(), re.cpu().numpy().astype(np.float64), te.cpu().numpy().astype(np.float64)
+    if callable(icp):  # e.g. a wrapper around o3d.registration_icp: (item, T_init) -> T
+        for i, it in enumerate(its):
+            refined = np.asarray(icp(it, T_h[i]), dtype=np.float32)
+            r1, t1 = ops.transformation_error_batched(torch.from_numpy(refined[None]).to(device), T_gt_d[i:i + 1].contiguous())
+            if r1.item() <= re_h[i] and t1.item() <= te_h[i]:
+                T_h[i], re_h[i], te_h[i] = refined, r1.item(), t1.item()
     preds = batch.unpack_src(src_pred)
+    loss = np.array([net.loss(preds[i][None], srcs[i][None], it[2][None].to(device), it[3][None].to(device)).item()
+                     for i, it in enumerate(its)])
+    return T_h, T_gt.numpy(), re_h, te_h, loss
+
+
+def evaluate_items(net, items: Sequence[tuple], pair_ids: Sequence[int], corr: str = "tgt", dis_thresh: float = 0.1,
+                   icp=None, device: Optional[torch.device] = None, pred_hook: Optional[Callable] = None) -> np.ndarray:
+    """One 3DMatch-family batch: items are the reference's 9-tuples.  Returns metric rows [B, 8] (dist.ROW_WIDTH).
+    pred_hook(batch, src_pred, pair_ids) -> src_pred may replace the network's prediction (used for the
+    "registered src + noise" throughput/metric variant of SURVEY.md section 8d and by the parity tests)."""
+    its = [_strip(it) for it in items]
+    core = [(it[0], it[1], it[2], it[3], it[4], it[7]) for it in its]
+    centers = [it[3] for it in its]  # src_center = trans^T, evaluate_3d_match.py:84
+    T_h, T_gt, re_h, te_h, loss = register_items(net, core, centers, pair_ids, corr, dis_thresh, icp, device=device,
+                                                 pred_hook=pred_hook)
     rows = np.zeros((len(its), sdist.ROW_WIDTH), dtype=np.float64)
     for i, it in enumerate(its):
-        transform, re_i, te_i = T_h[i], float(re_h[i]), float(te_h[i])
-        if icp is not None:  # evaluate_3d_match.py:106-119: accept the refinement only if it improves RE and TE
-            refined = icp(it, transform)
-            r1, t1 = ops.transformation_error_batched(torch.from_numpy(refined[None]).float().to(device), T_gt[i:i + 1].to(device))
-            if r1.item() <= re_i and t1.item() <= te_i:
-                transform, re_i, te_i = refined, float(r1.item()), float(t1.item())
-        rmse = math.sqrt(max(RMSE(np.linalg.inv(T_gt[i].numpy()) @ transform, it[6]), 0.0))
-        loss = net.loss(preds[i][None], srcs[i][None], it[2][None].to(device), it[3][None].to(device)).item()
-        rows[i] = [pair_ids[i], it[8], float(abs(it[5][1] - it[5][0]) > 1), float(rmse < 0.2), re_i, te_i, rmse, loss]
+        rmse = math.sqrt(max(RMSE(np.linalg.inv(T_gt[i]) @ T_h[i], it[6]), 0.0))  # evaluate_3d_match.py:122
+        rows[i] = [pair_ids[i], it[8], float(abs(it[5][1] - it[5][0]) > 1), float(rmse < 0.2), re_h[i], te_h[i], rmse, loss[i]]
     return rows
 
 
 def evaluate_loader(net, loader: Iterable, corr: str = "tgt", dis_thresh: float = 0.1,
-                    re_static_method: str = "median", batch_pairs: int = 32, icp: Optional[Callable] = None,
+                    re_static_method: str = "median", batch_pairs: int = 32, icp=None,
                     verbose: bool = True, pred_hook: Optional[Callable] = None):
     """evaluate_3d_match.py:53-171.  ``loader`` is a dataset or DataLoader of the reference's 9-tuples.
     With torch.distributed initialised the pairs are sharded round-robin over ranks and the per-pair rows

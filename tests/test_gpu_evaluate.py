@@ -146,3 +146,40 @@ def test_evaluate_loader_with_gpu_icp_only_improves():
     assert (ref[:, sdist.COL_RE] <= base[:, sdist.COL_RE] + 1e-6).all()
     assert (ref[:, sdist.COL_TE] <= base[:, sdist.COL_TE] + 1e-9).all()
     assert (ref[:, sdist.COL_TE] < base[:, sdist.COL_TE]).any()  # the accept rule fires on at least one pair
+
+
+def test_kitti_harness_large_clouds():
+    """BASELINE config 4 size (voxel 0.7, ~13-16k points per cloud): the KITTI loop with bbox normalisation,
+    dis_thresh 1.5, src_center = -(R^T t)^T, GPU ICP (radius 1 m, early exit), success = RE <= 5 and TE <= 2."""
+    from scream_amd.evaluate_kitti import SyntheticKittiPairs, evaluate
+    from scream_amd.model import PointTransformer
+    net = PointTransformer(256, 1, 1)
+    net.load_state_dict(make_state_dict(3, 256, 1, 1))
+    net = net.to(DEV).eval()
+    ds = SyntheticKittiPairs(2, seed0=5)
+    items = [ds[i] for i in range(2)]
+    assert all(10000 < it[0].shape[0] < 20000 for it in items)
+
+    def hook(batch, src_pred, ids):  # registered src + 5 cm noise
+        out = src_pred.clone()
+        for k, i in enumerate(ids):
+            src, tgt, rot, trans, s, c = items[i]
+            rng = np.random.default_rng(i)
+            reg = (rot @ src.T + trans).T + torch.from_numpy(rng.normal(scale=0.05 * s, size=src.shape).astype(np.float32))
+            r0 = int(batch.cloud_row0_host[k])
+            out[r0:r0 + src.shape[0]] = reg.to(DEV)
+        return out
+
+    loss, rre, rte, rate = evaluate(net, ds, icp="gpu", batch_pairs=2, verbose=False, pred_hook=hook)
+    assert rate == 1.0 and rre < 0.5 and rte < 0.2
+    # same pairs through the oracle (no ICP) agree on RE/TE
+    loss0, rre0, rte0, rate0 = evaluate(net, ds, icp=None, batch_pairs=1, verbose=False, pred_hook=hook)
+    want_re, want_te = [], []
+    for i, (src, tgt, rot, trans, s, c) in enumerate(items):
+        rng = np.random.default_rng(i)
+        pred = (rot @ src.T + trans).T + torch.from_numpy(rng.normal(scale=0.05 * s, size=src.shape).astype(np.float32))
+        d, idx, valid = O.nn_search(pred[None], tgt[None], s, 1.5)
+        A, B = O.gather_correspondences(src[None], tgt[None], pred[None], idx, valid, s, c, "tgt")
+        re, te = O.transformation_error(O.rigid_transform_3d(A, B)[0], O.gt_pose_metric(rot, trans, s, c))
+        want_re.append(re.item()); want_te.append(te.item())
+    assert abs(rre0 - np.mean(want_re)) < 0.05 and abs(rte0 - np.mean(want_te)) < 2e-3 and rate0 == 1.0
