@@ -23,7 +23,7 @@ import torch
 
 from . import dist as sdist
 from . import ops
-from .data import SCENE_NAMES
+from .data import SCENE_NAMES, collate_pairs
 from .geometry import processbar, register_batch
 from .packing import PackedBatch
 
@@ -162,7 +162,7 @@ def evaluate_items(net, items: Sequence[tuple], pair_ids: Sequence[int], corr: s
 
 def evaluate_loader(net, loader: Iterable, corr: str = "tgt", dis_thresh: float = 0.1,
                     re_static_method: str = "median", batch_pairs: int = 32, icp=None,
-                    verbose: bool = True, pred_hook: Optional[Callable] = None):
+                    verbose: bool = True, pred_hook: Optional[Callable] = None, num_workers: int = 0):
     """evaluate_3d_match.py:53-171.  ``loader`` is a dataset or DataLoader of the reference's 9-tuples.
     With torch.distributed initialised the pairs are sharded round-robin over ranks and the per-pair rows
     are all-gathered once at the end; every rank returns the same (point_trans_loss, rre, rte, rr)."""
@@ -172,9 +172,14 @@ def evaluate_loader(net, loader: Iterable, corr: str = "tgt", dis_thresh: float 
     mine = sdist.shard_indices(n, rank, world)
     rows: List[np.ndarray] = []
     done = 0
-    for b0 in range(0, len(mine), batch_pairs):
-        ids = mine[b0:b0 + batch_pairs]
-        r = evaluate_items(net, [dataset[i] for i in ids], ids, corr, dis_thresh, icp, pred_hook=pred_hook)
+    # var-len batches are lists of items; worker processes overlap file I/O + normalisation (or synthetic
+    # generation) with the GPU work of the previous batch, pinned so the H2D copies are asynchronous
+    batches = torch.utils.data.DataLoader(torch.utils.data.Subset(dataset, mine), batch_size=batch_pairs, shuffle=False,
+                                          collate_fn=collate_pairs, num_workers=num_workers,
+                                          pin_memory=num_workers > 0 and torch.cuda.is_available())
+    for items in batches:
+        ids = mine[done:done + len(items)]
+        r = evaluate_items(net, items, ids, corr, dis_thresh, icp, pred_hook=pred_hook)
         rows.append(r)
         done += len(ids)
         if verbose and rank == 0:
