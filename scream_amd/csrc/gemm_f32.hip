@@ -36,8 +36,6 @@ namespace {
 
 constexpr int BM = 128;
 constexpr int BN = 256;
-constexpr int BK = 32;
-constexpr int WTILE = BN * BK;  // floats per W tile buffer (unpadded, swizzled)
 constexpr int THREADS = 256;
 constexpr int MAX_GRID = 512;   // 256 CUs x 2 resident blocks
 
@@ -55,12 +53,19 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int EPI>
+// BK is a template parameter only so that the staging geometry below is written once; BK = 32 is what ships
+// (BK = 64 needs 128 KiB of LDS -> one block per CU: measured 117 vs 130 TFLOP/s, profiles/r01_gemm_ablation.txt).
+template <int EPI, int BK>
 __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                              const float* __restrict__ W,
                                                              float* __restrict__ C, int64_t ldc, int n_tiles,
                                                              unsigned total_tiles, int K, EpiArgs ep) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * WTILE];  // 64 KiB: two W tiles; buffer 1 doubles as epilogue slabs
+    constexpr int WTILE = BN * BK;   // floats per W tile buffer (unpadded, swizzled)
+    constexpr int NJ = BK / 8;       // 16-byte chunks per lane per k-tile
+    constexpr int NC = BK / 4;       // 16-byte chunks per W row
+    constexpr int RPI = 64 / NC;     // W rows per DMA wave-instruction (64 lanes x 16 B = 1 KiB)
+    constexpr int NQ = BN / RPI / 4; // DMA instructions per wave per k-tile
+    __shared__ __attribute__((aligned(16))) float smem[2 * WTILE];  // two W tiles; buffer 1 doubles as epilogue slabs
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -76,29 +81,29 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
         return (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (v >> 3);
     };
 
-    // W DMA: wave-instruction q (0..7) of this wave fills LDS rows (wave*8+q)*8 .. +7 (1 KiB, lane-linear):
-    // lane -> row nq = (wave*8+q)*8 + (lane>>3), destination chunk c' = lane & 7, source chunk c = c' ^ ((nq>>1)&7)
-    // where (nq>>1)&7 = (4q + (lane>>4)) & 7, i.e. one value for even q and that value ^ 4 for odd q.
-    const int c_even = (lane & 7) ^ ((lane >> 4) & 7);
-    const int64_t w_qstride = (int64_t)8 * K;
-    // B fragment read: row n = tn*32 + r, chunk (half*4 + j) -> c' = (half*4 + j) ^ ((r >> 1) & 7)
-    const int sw = (r >> 1) & 7;
-    int boff[4];
+    // W DMA: wave-instruction q of this wave fills LDS rows (wave*NQ+q)*RPI .. +RPI-1 (1 KiB, lane-linear):
+    // lane -> row nq = (wave*NQ+q)*RPI + lane/NC, destination chunk c' = lane % NC, source chunk c = c' ^ swz(nq)
+    // with swz(n) = (n >> 1) & 7 for 128-byte rows (BK 32) and n & 15 for 256-byte rows (BK 64): the 16 lanes of a
+    // ds_read_b128 group (16 distinct rows mod 16, one chunk index) then cover 16 distinct 16-byte bank slots.
+    auto swz = [](int n) { return BK == 32 ? ((n >> 1) & 7) : (n & 15); };
+    const int64_t w_qstride = (int64_t)RPI * K;
+    // B fragment read: row n = tn*32 + r, chunk (half*NJ + j) -> c' = (half*NJ + j) ^ swz(r)
+    int boff[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) boff[j] = r * BK + (((half * 4 + j) ^ sw) << 2);
+    for (int j = 0; j < NJ; ++j) boff[j] = r * BK + (((half * NJ + j) ^ swz(r)) << 2);
 
     auto dma_w = [&](const float* gw, int buf, int kt) {
         const float* src = gw + (int64_t)kt * BK;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int c = (q & 1) ? (c_even ^ 4) : c_even;
+        for (int q = 0; q < NQ; ++q) {
+            const int c = (lane % NC) ^ swz(q * RPI + lane / NC);  // (wave*NQ*RPI is a multiple of 16)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + q * w_qstride + c * 4),
-                                             (lptr_t)(smem + buf * WTILE + (wave * 8 + q) * 256), 16, 0, 0);
+                                             (lptr_t)(smem + buf * WTILE + (wave * NQ + q) * 256), 16, 0, 0);
         }
     };
     // A: lane (r, half) streams 64 contiguous bytes of its row per k-tile
-    auto a_ptr = [&](int64_t m0) { return A + (m0 + wave * 32 + r) * lda + half * 16; };
-    auto w_ptr = [&](int n0) { return W + (int64_t)(n0 + wave * 64 + (lane >> 3)) * K; };
+    auto a_ptr = [&](int64_t m0) { return A + (m0 + wave * 32 + r) * lda + half * (BK / 2); };
+    auto w_ptr = [&](int n0) { return W + (int64_t)(n0 + wave * 64 + lane / NC) * K; };
 
     const int KT = K / BK;  // even (host check): every output tile starts on LDS buffer 0 / register set a0
     unsigned v = blockIdx.x;
@@ -108,10 +113,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
     const float* ga = a_ptr(m0);
     const float* gw = w_ptr(n0);
 
-    f32x4 a0[4], a1[4];  // A fragments of the current / next k-tile (named, so indices stay static)
+    f32x4 a0[NJ], a1[NJ];  // A fragments of the current / next k-tile (named, so indices stay static)
     dma_w(gw, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a0[j] = ld4(ga + j * 4);
+    for (int j = 0; j < NJ; ++j) a0[j] = ld4(ga + j * 4);
     __syncthreads();  // with an LDS-DMA in flight hipcc drains vmcnt(0) here: k-tile 0 has landed for every wave
 
     for (;;) {
@@ -122,25 +127,26 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
             for (int e = 0; e < 16; ++e) acc[tn][e] = 0.f;
 
         // one k-tile: prefetch k-tile kt+1 (DMA + A registers), 128 MFMAs on k-tile kt, barrier
-        auto step = [&](int kt, int buf, f32x4 (&ac)[4], f32x4 (&an)[4]) {
+        auto step = [&](int kt, int buf, f32x4 (&ac)[NJ], f32x4 (&an)[NJ]) {
             // Retire the loads of this tile's A registers HERE, while nothing younger is in flight (they were
             // issued a whole tile ago and the barrier already drained them): with an LDS-DMA outstanding hipcc
             // would otherwise put s_waitcnt vmcnt(0) in front of the first MFMA and serialise tile t+1's
             // transfer with tile t's math.
-            asm volatile("" : "+v"(ac[0]), "+v"(ac[1]), "+v"(ac[2]), "+v"(ac[3]));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(ac[j]));
             if (kt + 1 < KT) {
                 dma_w(gw, buf ^ 1, kt + 1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) an[j] = ld4(ga + (kt + 1) * BK + j * 4);
+                for (int j = 0; j < NJ; ++j) an[j] = ld4(ga + (kt + 1) * BK + j * 4);
             }
             const float* wb = smem + buf * WTILE;
             f32x4 fb[2][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) fb[0][t] = ld4(wb + t * 32 * BK + boff[0]);
 #pragma unroll
-            for (int hc = 0; hc < 8; ++hc) {  // half-chunk hc: j = hc >> 1, N-tiles (hc & 1)*4 .. +3
+            for (int hc = 0; hc < 2 * NJ; ++hc) {  // half-chunk hc: j = hc >> 1, N-tiles (hc & 1)*4 .. +3
                 const int cur = hc & 1, nxt = cur ^ 1;
-                if (hc + 1 < 8) {
+                if (hc + 1 < 2 * NJ) {
                     const int j2 = (hc + 1) >> 1, th2 = (hc + 1) & 1;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) fb[nxt][t] = ld4(wb + (th2 * 4 + t) * 32 * BK + boff[j2]);
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
         if (EPI != SCREAM_EPI_RES_LN && has_next) {
             dma_w(gw, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a0[j] = ld4(ga + j * 4);
+            for (int j = 0; j < NJ; ++j) a0[j] = ld4(ga + j * 4);
         }
 
         // ---- epilogue (wave-private) ---------------------------------------------------------------------------
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
         if (EPI == SCREAM_EPI_RES_LN) {
             dma_w(gw, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a0[j] = ld4(ga + j * 4);
+            for (int j = 0; j < NJ; ++j) a0[j] = ld4(ga + j * 4);
         }
         __syncthreads();  // next tile's k-tile 0 landed (vmcnt(0)); every wave is done with its slab
     }
@@ -270,7 +276,7 @@ int launch(const float* A, int64_t lda, const float* W, float* C, int64_t ldc, i
     if (total == 0) return 0;
     SCREAM_REQUIRE(total < (1ll << 31), SCREAM_EUNSUPPORTED);
     const unsigned grid = total < MAX_GRID ? (unsigned)total : (unsigned)MAX_GRID;
-    gemm_f32_kernel<EPI><<<dim3(grid), dim3(THREADS), 0, st>>>(A, lda, W, C, ldc, n_tiles, (unsigned)total, K, ep);
+    gemm_f32_kernel<EPI, 32><<<dim3(grid), dim3(THREADS), 0, st>>>(A, lda, W, C, ldc, n_tiles, (unsigned)total, K, ep);
     SCREAM_LAUNCH_CHECK();
     return 0;
 }
@@ -282,7 +288,7 @@ extern "C" int scream_gemm_f32(const float* A, int64_t lda, const float* W, floa
                                const float* residual, int64_t ldr, const float* gamma, const float* beta,
                                void* stream) {
     SCREAM_REQUIRE(A && W && C, SCREAM_EINVAL);
-    SCREAM_REQUIRE(M >= 0 && M % BM == 0 && N > 0 && N % BN == 0 && K > 0 && K % (2 * BK) == 0, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE(M >= 0 && M % BM == 0 && N > 0 && N % BN == 0 && K > 0 && K % 64 == 0, SCREAM_EUNSUPPORTED);
     SCREAM_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0 && ldc % 4 == 0, SCREAM_EINVAL);
     SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(C) & 15) == 0, SCREAM_EINVAL);
