@@ -42,7 +42,8 @@ enum {
     SCREAM_EPI_ELU1 = 1,      /* columns < n_act: elu(x)+1 (transformer.py:7-8,28-29); rest plain */
     SCREAM_EPI_RELU = 2,      /* relu (transformer.py:66) */
     SCREAM_EPI_BIAS_RELU = 3, /* + bias, relu (pointnet.py:28-31) */
-    SCREAM_EPI_RES_LN = 4     /* LayerNorm(C + residual) * gamma + beta, N == 256 (transformer.py:84,88) */
+    SCREAM_EPI_RES_LN = 4,    /* LayerNorm(C + residual) * gamma + beta, N == 256 (transformer.py:84,88) */
+    SCREAM_EPI_QKV = 5        /* internal to scream_gemm_qkv_f32 */
 };
 
 /* Library / build identification: "scream_hip gfx950 <abi>"; abi bumps on any signature change. */
@@ -57,6 +58,22 @@ int scream_gemm_f32(const float* A, int64_t lda, const float* W, float* C, int64
                     int64_t M, int32_t N, int32_t K, int32_t epilogue, int32_t n_act,
                     const float* bias, const float* residual, int64_t ldr,
                     const float* gamma, const float* beta, void* stream);
+
+/* ---- A2 + A3 (reduce) fused: q/k/v projections whose key/value tiles never leave the chip.
+ * Replaces models/transformer.py:79-81 together with :28-29 (elu+1) and :38-40 (values / v_length, K^T V, K.sum).
+ * W [N,K] is laid out [ q (n_q = 256 rows, or 0 rows for the cross layers' key/value-only call) |
+ * k heads 0-3 | v heads 0-3 | k heads 4-7 | v heads 4-7 ] (128 rows each), so one 256-wide tile holds K and V of
+ * four heads for the same 128 tokens.  Query tiles are stored as elu(q)+1 into Q [M, ldq]; key/value tiles are
+ * reduced in the epilogue straight from the MFMA accumulators into kv_partial [M/128][8][33*32] (per 128-row
+ * tile and head: K'^T (V/S) as [d][v], then Ksum[d]); rows past the cloud's length are masked.  A's row 0 is
+ * packed row `row_base`; tile_cloud / cloud_row0 / cloud_len describe the packed batch (absolute rows).
+ * scream_kv_finalize then adds the tiles of every cloud in order. */
+int scream_gemm_qkv_f32(const float* A, int64_t lda, const float* W, float* Q, int64_t ldq, int64_t M,
+                        int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
+                        const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
+                        float* kv_partial, void* stream);
+int scream_kv_finalize(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
+                       int64_t row_base, int32_t cloud_begin, int32_t n_kv, float* kv_out, void* stream);
 
 /* ---- A1: feats = LayerNorm(PE_sine(xyz) + W_e (xyz - center[cloud]) + b_e)
  * Replaces models/pointnet.py:45-48 (+ models/transformer.py:157-179).  xyz [rows,3] packed;
@@ -92,7 +109,7 @@ int scream_coor_head(const float* X, const float* W, const float* b, float* out,
 /* ---- Whole forward pass of PointTransformer over a packed batch (A1-A6).
  * Replaces models/pointnet.py:38-60 for B pairs at once (the reference asserts B == 1, :39-40). */
 typedef struct {
-    const float* wqkv; /* [768,256]: rows 0-255 q_proj, 256-511 k_proj, 512-767 v_proj */
+    const float* wqkv; /* [768,256]: q_proj | k_proj[0:128] | v_proj[0:128] | k_proj[128:256] | v_proj[128:256] */
     const float* wm;   /* merge [256,256] */
     const float* w1;   /* mlp.0 [1024,256] */
     const float* w2;   /* mlp.2 [256,1024] */

@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscream_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -43,6 +43,8 @@ SIGNATURES = {
     "scream_version": (C.c_char_p, []),
     "scream_abi_version": (C.c_int, []),
     "scream_gemm_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, I32, V, V, I64, V, V, V]),
+    "scream_gemm_qkv_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, V, V, V, I64, V, V]),
+    "scream_kv_finalize": (C.c_int, [V, V, V, I64, I32, I32, V, V]),
     "scream_pe_embed_ln": (C.c_int, [V, V, V, V, V, V, V, V, V, I64, V]),
     "scream_kv_reduce": (C.c_int, [V, V, I64, I64, V, V, I32, I32, I32, V, V, V]),
     "scream_attn_apply": (C.c_int, [V, I64, V, V, I32, V, V, I64, I64, V]),

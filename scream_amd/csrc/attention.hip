@@ -84,6 +84,40 @@ __global__ __launch_bounds__(256) void kv_final_kernel(const float* __restrict__
     }
 }
 
+// Final sum of the per-128-row-tile partials written by the fused q/k/v GEMM epilogue (scream_gemm_qkv_f32).
+// grid n_kv * 8; block 256.  Same output layout as kv_final_kernel.
+__global__ __launch_bounds__(256) void kv_finalize_tiles_kernel(const float* __restrict__ partial,
+                                                               const int32_t* __restrict__ cloud_row0,
+                                                               const int32_t* __restrict__ cloud_len, int64_t row_base,
+                                                               int cloud_begin, float* __restrict__ kv_out) {
+    const int kvi = blockIdx.x / NH, h = blockIdx.x % NH;
+    const int cloud = cloud_begin + kvi;
+    const int t0 = (int)((cloud_row0[cloud] - row_base) / SCREAM_ROW_TILE);
+    const int nt = (cloud_len[cloud] + SCREAM_ROW_TILE - 1) / SCREAM_ROW_TILE;
+    const float* p = partial + ((int64_t)t0 * NH + h) * KV_ELEMS;
+    float* o = kv_out + ((int64_t)cloud * NH + h) * KV_ELEMS;
+    const float S = (float)cloud_len[cloud];
+    for (int i = threadIdx.x; i < KV_ELEMS; i += 256) {
+        // eight independent chains (tile c goes to chain c % 8) keep eight loads in flight; the combination order
+        // is fixed, so the result is deterministic
+        float s8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] = 0.f;
+        for (int c = 0; c < nt; c += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c + u < nt) s8[u] += p[(int64_t)(c + u) * NH * KV_ELEMS + i];
+        }
+        const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        if (i < HD * HD) {
+            const int dd = i / HD, v = i % HD;
+            o[v * HD + dd] = s / S;  // values / v_length (models/transformer.py:38-39), applied to the sum
+        } else {
+            o[i] = s;
+        }
+    }
+}
+
 // grid rows/128; block 256 = 4 waves, wave w owns heads 2w and 2w+1.
 constexpr int QS_LD = 260;  // 256 + 4: ds_read_b128 over 16 rows hits 16 distinct 4-bank slots
 constexpr int KT_LD = 36;
@@ -171,6 +205,17 @@ extern "C" int scream_kv_reduce(const float* Kf, const float* Vf, int64_t ld, in
                                                                     cloud_begin, max_chunks, partial);
     SCREAM_LAUNCH_CHECK();
     kv_final_kernel<<<dim3(n_kv * NH), dim3(256), 0, st>>>(partial, cloud_len, cloud_begin, max_chunks, kv_out);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int scream_kv_finalize(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
+                                  int64_t row_base, int32_t cloud_begin, int32_t n_kv, float* kv_out, void* stream) {
+    SCREAM_REQUIRE(kv_partial && cloud_row0 && cloud_len && kv_out, SCREAM_EINVAL);
+    SCREAM_REQUIRE(n_kv >= 0 && cloud_begin >= 0 && row_base >= 0, SCREAM_EINVAL);
+    if (n_kv == 0) return 0;
+    kv_finalize_tiles_kernel<<<dim3(n_kv * NH), dim3(256), 0, as_stream(stream)>>>(kv_partial, cloud_row0, cloud_len,
+                                                                                   row_base, cloud_begin, kv_out);
     SCREAM_LAUNCH_CHECK();
     return 0;
 }

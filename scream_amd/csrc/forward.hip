@@ -16,7 +16,7 @@ constexpr int D = SCREAM_D_MODEL;
 constexpr int KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;
 
 struct Workspace {
-    float *x0, *x1, *qkv, *att, *m1, *hid, *kvp, *kv;
+    float *x0, *x1, *q, *att, *m1, *hid, *kvp, *kv;
     int64_t bytes;
 };
 
@@ -30,11 +30,11 @@ Workspace carve(void* base, int64_t rows_total, int32_t n_pairs, int32_t max_chu
     };
     w.x0 = take(rows_total * D);
     w.x1 = take(rows_total * D);
-    w.qkv = take(rows_total * 3 * D);
+    w.q = take(rows_total * D);
     w.att = take(rows_total * D);
     w.m1 = take(rows_total * D);
     w.hid = take(rows_total * 4 * D);
-    w.kvp = take((int64_t)2 * n_pairs * max_chunks * SCREAM_NHEAD * KV_ELEMS);
+    w.kvp = take(rows_total / SCREAM_ROW_TILE * SCREAM_NHEAD * KV_ELEMS);  // one K^T V partial per 128-row tile and head
     w.kv = take((int64_t)2 * n_pairs * SCREAM_NHEAD * KV_ELEMS);
     w.bytes = (p - reinterpret_cast<float*>(base)) * (int64_t)sizeof(float);
     return w;
@@ -95,18 +95,24 @@ int mha_tail(const Ctx& c, const scream_layer_t& L, const Workspace& w, const fl
     return 0;
 }
 
+enum { TR_QKV = 5 };
+
 // Self attention over rows [0, rows) whose clouds are [0, n_clouds)  (transformer.py:74-90 with q = k = v).
+// The q/k/v projection reduces K^T V in its epilogue, so K' and V never reach HBM.
 int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x,
              float* y, int64_t rows, int32_t n_clouds) {
-    TRY(gemm(c, x, D, L.wqkv, w.qkv, 3 * D, rows, 3 * D, D, SCREAM_EPI_ELU1, 2 * D, nullptr, nullptr, nullptr, nullptr));
+    {
+        Scope sc(c.tr, TR_QKV, rows, 3 * D, D, c.st);
+        TRY(scream_gemm_qkv_f32(x, D, L.wqkv, w.q, D, rows, 3 * D, D, D, b.tile_cloud, b.cloud_row0, b.cloud_len, 0,
+                                w.kvp, c.st));
+    }
     {
         Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
-        TRY(scream_kv_reduce(w.qkv + D, w.qkv + 2 * D, 3 * D, 0, b.cloud_row0, b.cloud_len, 0, n_clouds, b.max_chunks,
-                             w.kvp, w.kv, c.st));
+        TRY(scream_kv_finalize(w.kvp, b.cloud_row0, b.cloud_len, 0, 0, n_clouds, w.kv, c.st));
     }
     {
         Scope sc(c.tr, TR_ATTN_APPLY, rows, 0, 0, c.st);
-        TRY(scream_attn_apply(w.qkv, 3 * D, w.kv, b.tile_cloud, 0, b.cloud_len, w.att, D, rows, c.st));
+        TRY(scream_attn_apply(w.q, D, w.kv, b.tile_cloud, 0, b.cloud_len, w.att, D, rows, c.st));
     }
     return mha_tail(c, L, w, x, y, rows);
 }
@@ -115,27 +121,27 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
 int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x_src,
               const float* x_tgt, float* y) {
     const int64_t rs = b.rows_src, rt = b.rows_total - b.rows_src;
-    float* qb = w.qkv;             // [rs, 256]
-    float* kvb = w.qkv + rs * D;   // [rt, 512]
-    TRY(gemm(c, x_src, D, L.wqkv, qb, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr));
-    TRY(gemm(c, x_tgt, D, L.wqkv + (int64_t)D * D, kvb, 2 * D, rt, 2 * D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr,
-             nullptr, nullptr));
+    TRY(gemm(c, x_src, D, L.wqkv, w.q, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr));
+    {
+        Scope sc(c.tr, TR_QKV, rt, 2 * D, D, c.st);
+        TRY(scream_gemm_qkv_f32(x_tgt, D, L.wqkv + (int64_t)D * D, nullptr, 0, rt, 2 * D, D, 0, b.tile_cloud, b.cloud_row0,
+                                b.cloud_len, rs, w.kvp, c.st));
+    }
     {
         Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
-        TRY(scream_kv_reduce(kvb, kvb + D, 2 * D, rs, b.cloud_row0, b.cloud_len, b.n_pairs, b.n_pairs, b.max_chunks,
-                             w.kvp, w.kv, c.st));
+        TRY(scream_kv_finalize(w.kvp, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs, w.kv, c.st));
     }
     {
         Scope sc(c.tr, TR_ATTN_APPLY, rs, 0, 0, c.st);
-        TRY(scream_attn_apply(qb, D, w.kv, b.tile_cloud, b.n_pairs, b.cloud_len, w.att, D, rs, c.st));
+        TRY(scream_attn_apply(w.q, D, w.kv, b.tile_cloud, b.n_pairs, b.cloud_len, w.att, D, rs, c.st));
     }
     return mha_tail(c, L, w, x_src, y, rs);
 }
 
 }  // namespace
 
-extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi2"; }
-extern "C" int scream_abi_version(void) { return 2; }
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi3"; }
+extern "C" int scream_abi_version(void) { return 3; }
 
 extern "C" void* scream_trace_create(int32_t capacity) {
     if (capacity <= 0) return nullptr;

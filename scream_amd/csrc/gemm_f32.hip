@@ -46,7 +46,22 @@ struct EpiArgs {
     int64_t ldr;
     const float* gamma;
     const float* beta;
+    // SCREAM_EPI_QKV only
+    float* kv_partial;          // [M/128][8][33*32]
+    const int32_t* tile_cloud;  // cloud of each 128-row tile of the packed batch
+    const int32_t* cloud_row0;
+    const int32_t* cloud_len;
+    int64_t row_base;           // packed row of A's row 0
 };
+
+constexpr int KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;
+
+__device__ __forceinline__ void lds_barrier() {
+    // workgroup barrier that waits for this wave's LDS traffic only: a __syncthreads() would also drain the
+    // LDS-DMA prefetch of the next tile that is deliberately left in flight (vmcnt).
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+}
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
@@ -192,6 +207,46 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
             for (int j = 0; j < NJ; ++j) a0[j] = ld4(ga + j * 4);
         }
 
+        // ---- fused K^T V epilogue (SCREAM_EPI_QKV, key/value tiles) ------------------------------------------------
+        // A key/value tile holds, for four heads, K (columns 0-127) and V (columns 128-255) of the same 128 tokens.
+        // In the 32x32 accumulator layout lane = column and the registers walk the rows, which is exactly the A / B
+        // operand layout of v_mfma_f32_32x32x2_f32 with the TOKEN as the contraction index: KV_h += mfma(K'_h[e], V_h[e])
+        // over the 16 accumulator registers is sum_tokens K'[t,d] V[t,v] -- straight from registers, K' and V never
+        // reach HBM (models/transformer.py:38-41: the "nshd,nshv->nhdv" einsum and K.sum; the division by v_length, which
+        // the reference applies to V "to prevent fp16 overflow", is linear and is applied to the fp32 sum in scream_kv_finalize).
+        if (EPI == SCREAM_EPI_QKV && n0_cur >= ep.n_act) {
+            const int mt_local = (int)(m0_cur / BM);
+            const int cloud = ep.tile_cloud[(ep.row_base + m0_cur) / BM];
+            const int clen = ep.cloud_len[cloud];
+            const int valid_w = clen - (int)(ep.row_base + m0_cur - ep.cloud_row0[cloud]) - wave * 32;  // real tokens in this wave's rows
+            const int hb = (n0_cur - ep.n_act) / BN * 4;
+            float* part = ep.kv_partial + ((int64_t)mt_local * SCREAM_NHEAD + hb) * KV_ELEMS;
+            float* slabs = smem + WTILE;  // 4 waves x 1056 floats inside the free W buffer
+#pragma unroll
+            for (int hq = 0; hq < 4; ++hq) {
+                f32x16 kv;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) kv[e] = 0.f;
+                float ks = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float a = acc[hq][e];
+                    a = a > 0.f ? a + 1.0f : expf(a);                  // elu(k) + 1
+                    if (mfma32_row(e, half) >= valid_w) a = 0.f;       // padding rows do not exist
+                    kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[4 + hq][e], kv, 0, 0, 0);  // (1 / v_length is applied once, in scream_kv_finalize)
+                    ks += a;
+                }
+                ks += __shfl_xor(ks, 32);
+                float* sw = slabs + wave * KV_ELEMS;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sw[mfma32_row(e, half) * 32 + r] = kv[e];  // [d][v]
+                if (half == 0) sw[32 * 32 + r] = ks;
+                lds_barrier();
+                for (int i = tid; i < KV_ELEMS; i += THREADS)
+                    part[hq * KV_ELEMS + i] = (slabs[i] + slabs[KV_ELEMS + i]) + (slabs[2 * KV_ELEMS + i] + slabs[3 * KV_ELEMS + i]);
+                lds_barrier();
+            }
+        } else {
         // ---- epilogue (wave-private) ---------------------------------------------------------------------------
         // acc[tn][e]: row = wave*32 + mfma32_row(e, half), col = tn*32 + r.  The k-loop ended on a barrier and its
         // last k-tile used buffer 0's partner, so buffer 1 is free: each wave takes an 8-row slab of it.
@@ -233,7 +288,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
                         const float rstd = 1.0f / sqrtf(var + 1e-5f);
                         vv[i] = d * rstd * p0 + p1;
                     }
-                } else if (EPI == SCREAM_EPI_ELU1) {
+                } else if (EPI == SCREAM_EPI_ELU1 || EPI == SCREAM_EPI_QKV) {
                     if (act) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
@@ -257,6 +312,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        }  // standard epilogue
         if (!has_next) break;
         v = v_next;
         if (EPI == SCREAM_EPI_RES_LN) {
@@ -292,7 +348,7 @@ extern "C" int scream_gemm_f32(const float* A, int64_t lda, const float* W, floa
     SCREAM_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0 && ldc % 4 == 0, SCREAM_EINVAL);
     SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(C) & 15) == 0, SCREAM_EINVAL);
-    EpiArgs ep{n_act, bias, residual, ldr, gamma, beta};
+    EpiArgs ep{n_act, bias, residual, ldr, gamma, beta, nullptr, nullptr, nullptr, nullptr, 0};
     hipStream_t st = as_stream(stream);
     switch (epilogue) {
         case SCREAM_EPI_NONE:
@@ -313,4 +369,18 @@ extern "C" int scream_gemm_f32(const float* A, int64_t lda, const float* W, floa
         default:
             return SCREAM_EINVAL;
     }
+}
+
+extern "C" int scream_gemm_qkv_f32(const float* A, int64_t lda, const float* W, float* Q, int64_t ldq, int64_t M,
+                                   int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
+                                   const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
+                                   float* kv_partial, void* stream) {
+    SCREAM_REQUIRE(A && W && kv_partial && tile_cloud && cloud_row0 && cloud_len, SCREAM_EINVAL);
+    SCREAM_REQUIRE(M >= 0 && M % BM == 0 && N > 0 && N % BN == 0 && K > 0 && K % 64 == 0, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE((n_q == 0 || n_q == BN) && N == n_q + 2 * BN && row_base >= 0 && row_base % BM == 0, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE(n_q == 0 || (Q && ldq >= n_q && ldq % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0), SCREAM_EINVAL);
+    SCREAM_REQUIRE(lda >= K && lda % 4 == 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0, SCREAM_EINVAL);
+    EpiArgs ep{n_q, nullptr, nullptr, 0, nullptr, nullptr, kv_partial, tile_cloud, cloud_row0, cloud_len, row_base};
+    return launch<SCREAM_EPI_QKV>(A, lda, W, Q, ldq, M, N, K, ep, as_stream(stream));
 }

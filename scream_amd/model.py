@@ -106,7 +106,10 @@ class PointTransformer(nn.Module):
         mods = self._layer_modules()
         layers = (_lib.LayerT * len(mods))()
         for L, m in zip(layers, mods):
-            L.wqkv = dev_f32(torch.cat([m.q_proj.weight, m.k_proj.weight, m.v_proj.weight], dim=0))
+            # [q | k heads 0-3 | v heads 0-3 | k heads 4-7 | v heads 4-7]: a 256-wide GEMM tile then holds K and V of
+            # four heads for the same tokens, which is what the fused K^T V epilogue needs (include/scream_hip.h)
+            k, v = m.k_proj.weight, m.v_proj.weight
+            L.wqkv = dev_f32(torch.cat([m.q_proj.weight, k[:128], v[:128], k[128:], v[128:]], dim=0))
             L.wm = dev_f32(m.merge.weight)
             L.w1 = dev_f32(m.mlp[0].weight)
             L.w2 = dev_f32(m.mlp[2].weight)

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import check
 
-EPI_NONE, EPI_ELU1, EPI_RELU, EPI_BIAS_RELU, EPI_RES_LN = 0, 1, 2, 3, 4
+EPI_NONE, EPI_ELU1, EPI_RELU, EPI_BIAS_RELU, EPI_RES_LN, EPI_QKV = 0, 1, 2, 3, 4, 5
 ROW_TILE = 128
 KV_CHUNK = 256
 KV_ELEMS = 33 * 32
@@ -50,6 +50,25 @@ def gemm_f32(A: torch.Tensor, W: torch.Tensor, epilogue: int = EPI_NONE, n_act: 
                               _p(bias), _p(residual), residual.stride(0) if residual is not None else 0,
                               _p(gamma), _p(beta), _stream()), "scream_gemm_f32")
     return out
+
+
+def gemm_qkv(A: torch.Tensor, W: torch.Tensor, n_q: int, tile_cloud, cloud_row0, cloud_len, row_base: int):
+    """Fused q/k/v projection (scream_gemm_qkv_f32).  Returns (Q' [M,256] or None, kv_partial [M/128,8,1056])."""
+    M, K = A.shape
+    N = W.shape[0]
+    Q = torch.empty(M, n_q, device=A.device, dtype=torch.float32) if n_q else None
+    part = torch.empty(M // ROW_TILE, 8, KV_ELEMS, device=A.device, dtype=torch.float32)
+    check(_lib.load().scream_gemm_qkv_f32(_p(A), A.stride(0), _p(W), _p(Q), n_q, M, N, K, n_q,
+                                          _p(tile_cloud, torch.int32), _p(cloud_row0, torch.int32),
+                                          _p(cloud_len, torch.int32), row_base, _p(part), _stream()), "scream_gemm_qkv_f32")
+    return Q, part
+
+
+def kv_finalize(part, cloud_row0, cloud_len, row_base: int, cloud_begin: int, n_kv: int, n_clouds: int) -> torch.Tensor:
+    kv = torch.zeros(n_clouds, 8, KV_ELEMS, device=part.device, dtype=torch.float32)
+    check(_lib.load().scream_kv_finalize(_p(part), _p(cloud_row0, torch.int32), _p(cloud_len, torch.int32), row_base,
+                                         cloud_begin, n_kv, _p(kv), _stream()), "scream_kv_finalize")
+    return kv
 
 
 def pe_embed_ln(xyz, tile_cloud, center, dim_t, emb_w, emb_b, gamma, beta) -> torch.Tensor:

@@ -136,6 +136,40 @@ def test_kv_reduce_multichunk_vs_oracle():
     torch.testing.assert_close(kv[0, :, 32 * 32:], want["Ksum"][0], rtol=1e-5, atol=1e-4)
 
 
+def test_fused_qkv_projection_and_kv_reduce_vs_oracle():
+    """scream_gemm_qkv_f32 + scream_kv_finalize: Q' = elu(x Wq^T)+1 stored, K^T (V/S) and Ksum reduced from the
+    accumulators per cloud -- against the oracle's intermediates, two ragged clouds incl. padding rows."""
+    sd = make_state_dict(9, 256, 1, 1)
+    rng = np.random.default_rng(2)
+    lens = [300, 129]
+    row0 = [0, 384]
+    rows = 640
+    x = torch.zeros(rows, 256)
+    xs = [torch.from_numpy(rng.normal(size=(n, 256)).astype(np.float32)) for n in lens]
+    for r0, xc in zip(row0, xs):
+        x[r0:r0 + xc.shape[0]] = xc
+    x[300:384] = 3.0  # garbage in padding rows must not reach the reduction
+    q, k, v = (sd["stem.0.%s_proj.weight" % n] for n in "qkv")
+    W = torch.cat([q, k[:128], v[:128], k[128:], v[128:]], dim=0)
+    tile_cloud = dev(torch.tensor([0, 0, 0, 1, 1], dtype=torch.int32))
+    crow0, clen = dev(torch.tensor(row0, dtype=torch.int32)), dev(torch.tensor(lens, dtype=torch.int32))
+    Q, part = ops.gemm_qkv(dev(x), dev(W), 256, tile_cloud, crow0, clen, 0)
+    kv = ops.kv_finalize(part, crow0, clen, 0, 0, 2, 2).cpu()
+    for ci, (r0, xc) in enumerate(zip(row0, xs)):
+        want = {}
+        O.mh_attention(xc[None], xc[None], xc[None], sd, "stem.0.", want)
+        n = xc.shape[0]
+        torch.testing.assert_close(Q[r0:r0 + n].cpu().reshape(n, 8, 32), want["Q"][0], rtol=1e-5, atol=1e-5)
+        kvt = kv[ci, :, :1024].reshape(8, 32, 32)  # [h][v][d]
+        torch.testing.assert_close(kvt.permute(0, 2, 1), want["KV"][0], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(kv[ci, :, 1024:], want["Ksum"][0], rtol=1e-5, atol=1e-4)
+    # key/value-only form used by the cross layers (n_q = 0, rows offset by row_base)
+    Wkv = W[256:].contiguous()
+    _, part2 = ops.gemm_qkv(dev(x[384:]), dev(Wkv), 0, tile_cloud, crow0, clen, 384)
+    kv2 = ops.kv_finalize(part2, crow0, clen, 384, 1, 1, 2).cpu()
+    torch.testing.assert_close(kv2[1], kv[1], rtol=0, atol=0)
+
+
 # ----------------------------------------------------------------- A1-A6 whole forward pass
 def test_forward_vs_reference_golden(golden):
     g = golden("e2e")

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_host_side_argument_checks_need_no_gpu():
     lib = _lib.load()
-    assert lib.scream_forward_workspace_bytes(128, 256, 1, 1) > 256 * (256 * 4 + 768 + 1024) * 4
+    assert lib.scream_forward_workspace_bytes(128, 256, 1, 1) > 256 * (256 * 5 + 1024) * 4  # x0, x1, q, att, m1 + hidden
     assert lib.scream_forward_workspace_bytes(256, 128, 1, 1) == -1  # rows_total < rows_src
     # NULL pointers / bad shapes are rejected before any launch
     assert lib.scream_gemm_f32(None, 256, None, None, 256, 128, 256, 256, 0, 0, None, None, 0, None, None, None) == -1
