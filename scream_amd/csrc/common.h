@@ -35,10 +35,21 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     return v;
 }
 
+// Sum over the 64 lanes of a wave, result in every lane.  DPP inclusive scan (row_shr 1/2/4/8 inside each 16-lane
+// row, then row_bcast15 into rows 1/3 and row_bcast31 into rows 2/3) leaves the total in lane 63; six VALU
+// instructions and one v_readlane instead of six dependent ds_bpermute round trips through the LDS pipeline.
 __device__ __forceinline__ float wave_sum(float v) {
-    v = half_wave_sum(v);
-    v += __shfl_xor(v, 32);
-    return v;
+#define SCREAM_DPP_ADD(ctrl, row_mask)                                                                      \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, \
+                                                               0xf, true))
+    SCREAM_DPP_ADD(0x111, 0xf);  // row_shr:1 (out-of-row lanes read 0: bound_ctrl)
+    SCREAM_DPP_ADD(0x112, 0xf);  // row_shr:2
+    SCREAM_DPP_ADD(0x114, 0xf);  // row_shr:4
+    SCREAM_DPP_ADD(0x118, 0xf);  // row_shr:8  -> lane 15 of each row holds the row sum
+    SCREAM_DPP_ADD(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    SCREAM_DPP_ADD(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+#undef SCREAM_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ double wave_sum_f64(double v) {

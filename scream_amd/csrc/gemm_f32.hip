@@ -207,6 +207,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
             for (int j = 0; j < NJ; ++j) a0[j] = ld4(ga + j * 4);
         }
 
+        __builtin_amdgcn_s_setprio(2);  // the epilogue's LDS/VALU/store issue is otherwise starved by the partner block's MFMA stream
         // ---- fused K^T V epilogue (SCREAM_EPI_QKV, key/value tiles) ------------------------------------------------
         // A key/value tile holds, for four heads, K (columns 0-127) and V (columns 128-255) of the same 128 tokens.
         // In the 32x32 accumulator layout lane = column and the registers walk the rows, which is exactly the A / B
@@ -260,6 +261,13 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
             p1 = ld4(ep.beta + col);
         }
         const bool act = n0_cur < ep.n_act;  // n_act is a multiple of 256: uniform per tile
+        // RES_LN: the residual rows of half-chunk h+1 are requested before half-chunk h is processed, so their
+        // ~2 us first-touch latency is not paid eight times in a row
+        f32x4 rsd[2][4];
+        if (EPI == SCREAM_EPI_RES_LN) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rsd[0][i] = ld4(ep.residual + (m0_cur + wave * 32 + i) * ep.ldr + col);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {  // rows 8g .. 8g+7 of the wave's 32
 #pragma unroll
@@ -276,12 +284,14 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
                 for (int i = 0; i < 4; ++i) vv[i] = ld4(slab + (hh * 4 + i) * SLAB_LD + lane * 4);
                 const int64_t row0 = m0_cur + wave * 32 + 8 * g + 4 * hh;
                 if (EPI == SCREAM_EPI_RES_LN) {
-                    f32x4 res[4];
+                    const int hcur = (2 * g + hh) & 1;
+                    if (2 * g + hh + 1 < 8) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) res[i] = ld4(ep.residual + (row0 + i) * ep.ldr + col);
+                        for (int i = 0; i < 4; ++i) rsd[hcur ^ 1][i] = ld4(ep.residual + (row0 + 4 + i) * ep.ldr + col);
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        vv[i] += res[i];
+                        vv[i] += rsd[hcur][i];
                         const float mean = wave_sum((vv[i][0] + vv[i][1]) + (vv[i][2] + vv[i][3])) * (1.0f / 256.0f);
                         const f32x4 d = vv[i] - mean;
                         const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 256.0f);
@@ -313,6 +323,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
             __builtin_amdgcn_wave_barrier();
         }
         }  // standard epilogue
+        __builtin_amdgcn_s_setprio(0);
         if (!has_next) break;
         v = v_next;
         if (EPI == SCREAM_EPI_RES_LN) {
