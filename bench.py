@@ -115,9 +115,15 @@ def main():
     from scream_amd.packing import PackedBatch
     from scream_amd.synthetic import make_state_dict
 
-    rank, world, local = sdist.init_from_env("nccl")
+    # RCCL ("nccl") over xGMI in production.  SCREAM_BENCH_BACKEND=gloo + SCREAM_BENCH_SINGLE_DEVICE=1 exist only to
+    # rehearse the multi-rank control flow on a one-GPU box (ranks then share cuda:0 and exchange rows through the CPU).
+    backend = os.environ.get("SCREAM_BENCH_BACKEND", "nccl")
+    rank, world, local = sdist.init_from_env(backend)
+    if os.environ.get("SCREAM_BENCH_SINGLE_DEVICE", "0") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     lib = _lib.load()
 
     sd = make_state_dict(0, 256, 6, 6)
@@ -131,7 +137,7 @@ def main():
     c = torch.stack([it[5] for it in items]).to(dev)
     T_gt = torch.stack([gt_pose_metric(it[2], it[3], it[4], it[5]) for it in items]).to(dev)
     pair_ids = torch.arange(rank * B, (rank + 1) * B, device=dev, dtype=torch.float32)
-    gathered = [torch.empty(B, sdist.ROW_WIDTH, device=dev) for _ in range(world)] if world > 1 else None
+    gathered = [torch.empty(B, sdist.ROW_WIDTH, device=coll_dev) for _ in range(world)] if world > 1 else None
 
     def step(trace=None):
         src_pred = net.forward_packed(batch, trace=trace)                           # A1-A6
@@ -140,7 +146,7 @@ def main():
         if world > 1:  # the path's only exchange: per-pair metric rows
             rows = torch.zeros(B, sdist.ROW_WIDTH, device=dev)
             rows[:, 0], rows[:, 4], rows[:, 5] = pair_ids, re, te
-            tdist.all_gather(gathered, rows)
+            tdist.all_gather(gathered, rows.to(coll_dev))
         return re, te, n_corr
 
     def fence():
@@ -160,7 +166,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -173,12 +179,16 @@ def main():
     cnt = lib.scream_trace_read(trace, cap, ms, kind, mm, nn, kk)
     assert cnt > 0, "trace empty"
     lib.scream_trace_destroy(trace)
-    by = {}
+    by, by_shape = {}, {}
     for i in range(cnt):
         e = by.setdefault(kind[i], {"launches": 0, "ms": 0.0, "padded_flops": 0.0})
         e["launches"] += 1
         e["ms"] += ms[i]
         e["padded_flops"] += 2.0 * mm[i] * nn[i] * kk[i]
+        if kind[i] < 100:
+            e2 = by_shape.setdefault((kind[i], mm[i], nn[i], kk[i]), {"launches": 0, "ms": 0.0})
+            e2["launches"] += 1
+            e2["ms"] += ms[i]
     gemm_ms = sum(v["ms"] for k_, v in by.items() if k_ < 100)
     gemm_launches = sum(v["launches"] for k_, v in by.items() if k_ < 100)
     rows_true = sum(batch.src_len) + sum(batch.tgt_len)
@@ -192,6 +202,10 @@ def main():
         if k_ < 100:
             row["tflops_algorithmic"] = round(v["padded_flops"] * pad_eff / (v["ms"] * 1e-3) / 1e12, 2)
         by_kernel.append(row)
+    by_gemm_shape = [{"epilogue": k_[0], "M": int(k_[1]), "N": int(k_[2]), "K": int(k_[3]), "launches": v["launches"],
+                      "avg_ms": round(v["ms"] / v["launches"], 4),
+                      "tflops_padded": round(2.0 * k_[1] * k_[2] * k_[3] / (v["ms"] / v["launches"] * 1e-3) / 1e12, 1)}
+                     for k_, v in sorted(by_shape.items())]
 
     if rank == 0:
         total_pairs = B * world * args.steps
@@ -210,7 +224,8 @@ def main():
                          "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
                          "launches": gemm_launches, "avg_ms": round(gemm_ms / gemm_launches, 4),
                          "algorithmic_gflop_per_step": round(algo_flops_step / 1e9, 1),
-                         "row_padding_efficiency": round(pad_eff, 4), "by_kernel": by_kernel},
+                         "row_padding_efficiency": round(pad_eff, 4), "by_kernel": by_kernel,
+                         "by_gemm_shape": by_gemm_shape},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(items, sd, 16)
