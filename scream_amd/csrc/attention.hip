@@ -98,16 +98,18 @@ __global__ __launch_bounds__(256) void kv_finalize_tiles_kernel(const float* __r
     float* o = kv_out + ((int64_t)cloud * NH + h) * KV_ELEMS;
     const float S = (float)cloud_len[cloud];
     for (int i = threadIdx.x; i < KV_ELEMS; i += 256) {
-        // eight independent chains (tile c goes to chain c % 8) keep eight loads in flight; the combination order
-        // is fixed, so the result is deterministic
-        float s8[8];
+        // sixteen independent chains (tile c goes to chain c % 16) keep sixteen loads in flight; the combination
+        // order is fixed, so the result is deterministic
+        float s8[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s8[u] = 0.f;
-        for (int c = 0; c < nt; c += 8) {
+        for (int u = 0; u < 16; ++u) s8[u] = 0.f;
+        for (int c = 0; c < nt; c += 16) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (c + u < nt) s8[u] += p[(int64_t)(c + u) * NH * KV_ELEMS + i];
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += s8[u + 8];
         const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
         if (i < HD * HD) {
             const int dd = i / HD, v = i % HD;
