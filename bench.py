@@ -39,9 +39,16 @@ GEMM_NAMES = {0: "gemm_f32_kernel<EPI_NONE>", 1: "gemm_f32_kernel<EPI_ELU1> (cro
               103: "coor_head_kernel"}
 
 
+WORKLOAD = "3dmatch"
+
+
 def _gen(seed):
     from scream_amd.data import normalize_pair
-    from scream_amd.synthetic import make_3dmatch_pair
+    from scream_amd.synthetic import make_3dmatch_pair, make_kitti_pair, make_uniform_pair
+    if WORKLOAD == "kitti":      # BASELINE configs[3]: voxel 0.7, ~13-16k points per cloud, bbox normalisation
+        return normalize_pair(*make_kitti_pair(seed), "bbox")
+    if WORKLOAD == "uniform64k":  # BASELINE configs[4]: 65 536 uniform points per cloud
+        return normalize_pair(*make_uniform_pair(seed, 65536))
     src, tgt, T, idx, cov, scene = make_3dmatch_pair(seed)
     return normalize_pair(src, tgt, T)
 
@@ -93,6 +100,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gen-procs", type=int, default=0, help="worker processes for synthetic data (0 = auto)")
+    ap.add_argument("--workload", default="3dmatch", choices=["3dmatch", "kitti", "uniform64k"],
+                    help="3dmatch = BASELINE configs[1] (the headline, default); kitti / uniform64k = configs[3] / [4] stress runs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,6 +111,8 @@ def main():
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
 
+    global WORKLOAD
+    WORKLOAD = args.workload
     B = args.pairs
     items = make_items([rank * B + i for i in range(B)], args.gen_procs)  # before any GPU call (fork safety)
 
@@ -139,9 +150,11 @@ def main():
     pair_ids = torch.arange(rank * B, (rank + 1) * B, device=dev, dtype=torch.float32)
     gathered = [torch.empty(B, sdist.ROW_WIDTH, device=coll_dev) for _ in range(world)] if world > 1 else None
 
+    dis_thresh = 1.5 if args.workload == "kitti" else 0.1  # evaluate_kitti.py:109 / evaluate_3d_match.py:178
+
     def step(trace=None):
         src_pred = net.forward_packed(batch, trace=trace)                           # A1-A6
-        T, n_corr, idx, dmin, valid = register_batch(batch, src_pred, s, c, 0.1)    # A7-A9
+        T, n_corr, idx, dmin, valid = register_batch(batch, src_pred, s, c, dis_thresh)  # A7-A9
         re, te = ops.transformation_error_batched(T, T_gt)                          # A10
         if world > 1:  # the path's only exchange: per-pair metric rows
             rows = torch.zeros(B, sdist.ROW_WIDTH, device=dev)
@@ -214,9 +227,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic 3DMatch_test-like pairs, voxel 0.0625 m, "
-                                   "~5k points/cloud, batch-of-pairs=%d per GPU, A1-A10 per pair "
-                                   "(forward 6+6 layers d_model 256, 1-NN thresh 0.1, Kabsch, RE/TE), random-init weights seed 0" % B,
+            "config": {"workload": {"3dmatch": "BASELINE configs[1]: synthetic 3DMatch_test-like pairs, voxel 0.0625 m, ~5k points/cloud",
+                                    "kitti": "BASELINE configs[3]: synthetic KITTI_test-like pairs, voxel 0.7 m, ~13-16k points/cloud",
+                                    "uniform64k": "BASELINE configs[4]: 65 536 uniform points per cloud"}[args.workload]
+                                   + ", batch-of-pairs=%d per GPU, A1-A10 per pair (forward 6+6 layers d_model 256, 1-NN thresh %g, "
+                                     "Kabsch, RE/TE), random-init weights seed 0" % (B, dis_thresh),
                        "pairs_per_step_per_gpu": B, "mean_src_points": round(float(np.mean(batch.src_len)), 1),
                        "mean_tgt_points": round(float(np.mean(batch.tgt_len)), 1), "parallelism": "dp%d (pairs sharded, metric-row all-gather)" % world},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32; all epilogue instantiations; the fused K^T V epilogue's own MFMAs are not counted as algorithmic flops)",

@@ -85,8 +85,9 @@ __global__ __launch_bounds__(256) void kv_final_kernel(const float* __restrict__
 }
 
 // Final sum of the per-128-row-tile partials written by the fused q/k/v GEMM epilogue (scream_gemm_qkv_f32).
-// grid n_kv * 8; block 256.  Same output layout as kv_final_kernel.
-__global__ __launch_bounds__(256) void kv_finalize_tiles_kernel(const float* __restrict__ partial,
+// grid n_kv * 8; block 1024 (one element per thread: the sum is a chain of dependent loads, so parallelism across
+// elements is what hides the latency).  Same output layout as kv_final_kernel.
+__global__ __launch_bounds__(1024) void kv_finalize_tiles_kernel(const float* __restrict__ partial,
                                                                const int32_t* __restrict__ cloud_row0,
                                                                const int32_t* __restrict__ cloud_len, int64_t row_base,
                                                                int cloud_begin, float* __restrict__ kv_out) {
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void kv_finalize_tiles_kernel(const float* __r
     const float* p = partial + ((int64_t)t0 * NH + h) * KV_ELEMS;
     float* o = kv_out + ((int64_t)cloud * NH + h) * KV_ELEMS;
     const float S = (float)cloud_len[cloud];
-    for (int i = threadIdx.x; i < KV_ELEMS; i += 256) {
+    for (int i = threadIdx.x; i < KV_ELEMS; i += 1024) {
         // sixteen independent chains (tile c goes to chain c % 16) keep sixteen loads in flight; the combination
         // order is fixed, so the result is deterministic
         float s8[16];
@@ -216,7 +217,7 @@ extern "C" int scream_kv_finalize(const float* kv_partial, const int32_t* cloud_
     SCREAM_REQUIRE(kv_partial && cloud_row0 && cloud_len && kv_out, SCREAM_EINVAL);
     SCREAM_REQUIRE(n_kv >= 0 && cloud_begin >= 0 && row_base >= 0, SCREAM_EINVAL);
     if (n_kv == 0) return 0;
-    kv_finalize_tiles_kernel<<<dim3(n_kv * NH), dim3(256), 0, as_stream(stream)>>>(kv_partial, cloud_row0, cloud_len,
+    kv_finalize_tiles_kernel<<<dim3(n_kv * NH), dim3(1024), 0, as_stream(stream)>>>(kv_partial, cloud_row0, cloud_len,
                                                                                    row_base, cloud_begin, kv_out);
     SCREAM_LAUNCH_CHECK();
     return 0;

@@ -341,3 +341,22 @@ def test_register_pairs_full_size_vs_oracle():
         re_o, te_o = O.transformation_error(T_o, Tgt)
         re, te = ops.transformation_error_batched(T[i:i + 1].contiguous(), dev(Tgt)[None].contiguous())
         assert abs(re.item() - re_o.item()) < 0.05 and abs(te.item() - te_o.item()) < 1e-4
+
+
+def test_large_cloud_40k_points_forward_and_search():
+    """Robustness at sizes beyond KITTI (BASELINE configs[4] direction): one pair of 40k-point clouds through a
+    1+1-layer model; forward against the oracle, the search bit-exact against the chunked numpy model."""
+    from scream_amd.geometry import nn_search_pair
+    from scream_amd.synthetic import make_uniform_pair
+    from scream_amd.data import normalize_pair
+    net = build_net(8, 1, 1)
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    src, tgt, rot, trans, s, c = normalize_pair(*make_uniform_pair(1, 40000, 39000))
+    out = net(dev(src)[None], dev(tgt)[None], dev(trans.reshape(1, 1, 3)), s)[0][0].cpu()
+    want = O.point_transformer_forward(src[None], tgt[None], sd, trans.reshape(1, 1, 3))[0]
+    torch.testing.assert_close(out, want, rtol=5e-4, atol=1e-4)
+    reg = (rot @ src.T + trans).T
+    d, idx, valid = nn_search_pair(dev(reg), dev(tgt), s, 0.1)
+    de, ie, _ = O.nn_search_exact(reg.numpy(), tgt.numpy(), s, chunk=512)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ie)
+    np.testing.assert_array_equal(d.cpu().numpy(), de)
