@@ -80,7 +80,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
     constexpr int NC = BK / 4;       // 16-byte chunks per W row
     constexpr int RPI = 64 / NC;     // W rows per DMA wave-instruction (64 lanes x 16 B = 1 KiB)
     constexpr int NQ = BN / RPI / 4; // DMA instructions per wave per k-tile
-    __shared__ __attribute__((aligned(16))) float smem[2 * WTILE];  // two W tiles; buffer 1 doubles as epilogue slabs
+    __shared__ __attribute__((aligned(16))) float smem[2 * WTILE + 256];  // two W tiles (+1 KiB); buffer 1 doubles as epilogue slabs
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -222,29 +222,36 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
             const int valid_w = clen - (int)(ep.row_base + m0_cur - ep.cloud_row0[cloud]) - wave * 32;  // real tokens in this wave's rows
             const int hb = (n0_cur - ep.n_act) / BN * 4;
             float* part = ep.kv_partial + ((int64_t)mt_local * SCREAM_NHEAD + hb) * KV_ELEMS;
-            float* slabs = smem + WTILE;  // 4 waves x 1056 floats inside the free W buffer
+            float* slabs = smem + WTILE;  // 2 heads x 4 waves x 1056 floats: the free W buffer plus the 1 KiB tail
 #pragma unroll
-            for (int hq = 0; hq < 4; ++hq) {
-                f32x16 kv;
+            for (int hp = 0; hp < 2; ++hp) {  // two heads per round: 4 workgroup barriers per tile instead of 8
 #pragma unroll
-                for (int e = 0; e < 16; ++e) kv[e] = 0.f;
-                float ks = 0.f;
+                for (int hh2 = 0; hh2 < 2; ++hh2) {
+                    const int hq = hp * 2 + hh2;
+                    f32x16 kv;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float a = acc[hq][e];
-                    a = a > 0.f ? a + 1.0f : expf(a);                  // elu(k) + 1
-                    if (mfma32_row(e, half) >= valid_w) a = 0.f;       // padding rows do not exist
-                    kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[4 + hq][e], kv, 0, 0, 0);  // (1 / v_length is applied once, in scream_kv_finalize)
-                    ks += a;
+                    for (int e = 0; e < 16; ++e) kv[e] = 0.f;
+                    float ks = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float a = acc[hq][e];
+                        a = a > 0.f ? a + 1.0f : expf(a);                  // elu(k) + 1
+                        if (mfma32_row(e, half) >= valid_w) a = 0.f;       // padding rows do not exist
+                        kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[4 + hq][e], kv, 0, 0, 0);  // (1 / v_length is applied once, in scream_kv_finalize)
+                        ks += a;
+                    }
+                    ks += __shfl_xor(ks, 32);
+                    float* sw = slabs + (hh2 * 4 + wave) * KV_ELEMS;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sw[mfma32_row(e, half) * 32 + r] = kv[e];  // [d][v]
+                    if (half == 0) sw[32 * 32 + r] = ks;
                 }
-                ks += __shfl_xor(ks, 32);
-                float* sw = slabs + wave * KV_ELEMS;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sw[mfma32_row(e, half) * 32 + r] = kv[e];  // [d][v]
-                if (half == 0) sw[32 * 32 + r] = ks;
                 lds_barrier();
-                for (int i = tid; i < KV_ELEMS; i += THREADS)
-                    part[hq * KV_ELEMS + i] = (slabs[i] + slabs[KV_ELEMS + i]) + (slabs[2 * KV_ELEMS + i] + slabs[3 * KV_ELEMS + i]);
+                for (int i = tid; i < 2 * KV_ELEMS; i += THREADS) {
+                    const int hh2 = i >= KV_ELEMS ? 1 : 0, k = i - hh2 * KV_ELEMS;
+                    const float* s4 = slabs + hh2 * 4 * KV_ELEMS + k;
+                    part[(hp * 2 + hh2) * KV_ELEMS + k] = (s4[0] + s4[KV_ELEMS]) + (s4[2 * KV_ELEMS] + s4[3 * KV_ELEMS]);
+                }
                 lds_barrier();
             }
         } else {
