@@ -127,6 +127,10 @@ typedef struct {
     const float* c0_w; const float* c0_b; /* coor_mlp.0 [256,256],[256] */
     const float* c2_w; const float* c2_b; /* coor_mlp.2 */
     const float* c4_w; const float* c4_b; /* coor_mlp.4 [3,256],[3] */
+    /* NULL for PointTransformer (one stem for both clouds, models/pointnet.py:50-52).  DEMTransformer
+     * (models/pointnet.py:113-118,143-145): HOST array of n_self layers applied to the SECOND clouds (stem_dem) while
+     * layers_host[0..n_self) (stem_dsm) are applied to the first clouds only. */
+    const scream_layer_t* stem_tgt_layers_host;
 } scream_model_t;
 
 typedef struct {

@@ -5,6 +5,6 @@ signature (reference models/pointnet.py:8-99), backed by the MI355X kernels in `
     net = PointTransformer(d_model=256); net.to("cuda:0"); net.load_state_dict(torch.load(...)); net.eval()
     src_, imgs, transform = net(src, tgt, src_center, s, False, get_transform, filter)
 """
-from scream_amd.model import PointTransformer  # noqa: F401
+from scream_amd.model import DEMTransformer, PointTransformer  # noqa: F401
 
-__all__ = ["PointTransformer"]
+__all__ = ["PointTransformer", "DEMTransformer"]

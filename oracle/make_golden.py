@@ -120,6 +120,23 @@ def main():
         e2e[seed] = (src_, torch.from_numpy(tgt))
     np.savez(os.path.join(OUT, "e2e.npz"), **rec)
 
+    # ---- DEMTransformer, d_model=256 ---------------------------------------------
+    rec = {}
+    dem_cases = [(31, 1, 1, 120, 90), (32, 2, 2, 200, 257)]
+    rec["cases"] = np.array(dem_cases, dtype=np.int64)
+    for seed, ns, nc, n, m in dem_cases:
+        sd = make_state_dict(seed, 256, ns, nc, dem=True)
+        net = ref_pointnet.DEMTransformer(d_model=256, self_layer_num=ns, cross_layer_num=nc)
+        net.load_state_dict(sd, strict=True)
+        net.eval()
+        r2 = np.random.default_rng(seed)
+        dsm, demc = cloud(r2, n), cloud(r2, m)
+        with torch.no_grad():
+            out, imgs = net(torch.from_numpy(dsm), torch.from_numpy(demc), False)
+        assert imgs is None
+        rec["dsm_%d" % seed], rec["dem_%d" % seed], rec["out_%d" % seed] = dsm, demc, out.numpy()
+    np.savez(os.path.join(OUT, "dem.npz"), **rec)
+
     # ---- A7: thresholded 1-NN -----------------------------------------------------
     rec = {}
     src_, tgt = e2e[23]

@@ -125,6 +125,25 @@ def point_transformer_forward(src: torch.Tensor, tgt: torch.Tensor, sd: Dict[str
     return h @ sd["coor_mlp.4.weight"][:, :, 0].t() + sd["coor_mlp.4.bias"]
 
 
+def dem_transformer_forward(dsm: torch.Tensor, dem_coarse: torch.Tensor, sd: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """models/pointnet.py:134-153 (DEMTransformer): separate stems, raw coordinates embedded for both clouds."""
+    n_self = len({k.split(".")[1] for k in sd if k.startswith("stem_dsm.")})
+    n_cross2 = len({k.split(".")[1] for k in sd if k.startswith("cross.")})
+    sf = embed_prenorm(dsm, dsm, sd)
+    tf = embed_prenorm(dem_coarse, dem_coarse, sd)
+    for i in range(n_self):
+        sf = mh_attention(sf, sf, sf, sd, "stem_dsm.%d." % i)
+        tf = mh_attention(tf, tf, tf, sd, "stem_dem.%d." % i)
+    for i in range(n_cross2):
+        if i % 2 == 0:
+            sf = mh_attention(sf, sf, sf, sd, "cross.%d." % i)
+        else:
+            sf = mh_attention(sf, tf, tf, sd, "cross.%d.layer." % i)
+    h = torch.relu(sf @ sd["coor_mlp.0.weight"][:, :, 0].t() + sd["coor_mlp.0.bias"])
+    h = torch.relu(h @ sd["coor_mlp.2.weight"][:, :, 0].t() + sd["coor_mlp.2.bias"])
+    return h @ sd["coor_mlp.4.weight"][:, :, 0].t() + sd["coor_mlp.4.bias"]
+
+
 # --------------------------------------------------------------------------- A7
 def square_distance(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     """utils.py:72-78 (expanded form; materialises [B,N,M])."""

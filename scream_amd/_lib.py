@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscream_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -28,7 +28,8 @@ class ModelT(C.Structure):
     _fields_ = [("n_self", C.c_int32), ("n_cross", C.c_int32), ("dim_t", C.c_void_p), ("emb_w", C.c_void_p),
                 ("emb_b", C.c_void_p), ("pre_g", C.c_void_p), ("pre_b", C.c_void_p),
                 ("layers_host", C.POINTER(LayerT)), ("c0_w", C.c_void_p), ("c0_b", C.c_void_p),
-                ("c2_w", C.c_void_p), ("c2_b", C.c_void_p), ("c4_w", C.c_void_p), ("c4_b", C.c_void_p)]
+                ("c2_w", C.c_void_p), ("c2_b", C.c_void_p), ("c4_w", C.c_void_p), ("c4_b", C.c_void_p),
+                ("stem_tgt_layers_host", C.POINTER(LayerT))]
 
 
 class BatchT(C.Structure):

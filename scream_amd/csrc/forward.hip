@@ -88,33 +88,43 @@ int gemm(const Ctx& c, const float* A, int64_t lda, const float* W, float* C, in
 }
 
 // merge + norm1 + FFN + norm2 (models/transformer.py:83-88); x is the block input (residual of BOTH norms).
-int mha_tail(const Ctx& c, const scream_layer_t& L, const Workspace& w, const float* x, float* y, int64_t rows) {
-    TRY(gemm(c, w.att, D, L.wm, w.m1, D, rows, D, D, SCREAM_EPI_RES_LN, 0, nullptr, x, L.g1, L.b1));
-    TRY(gemm(c, w.m1, D, L.w1, w.hid, 4 * D, rows, 4 * D, D, SCREAM_EPI_RELU, 0, nullptr, nullptr, nullptr, nullptr));
-    TRY(gemm(c, w.hid, 4 * D, L.w2, y, D, rows, D, 4 * D, SCREAM_EPI_RES_LN, 0, nullptr, x, L.g2, L.b2));
+// x / y already point at packed row `row0`; the scratch buffers are indexed by packed row as well.
+int mha_tail(const Ctx& c, const scream_layer_t& L, const Workspace& w, const float* x, float* y, int64_t row0,
+             int64_t rows) {
+    float* att = w.att + row0 * D;
+    float* m1 = w.m1 + row0 * D;
+    float* hid = w.hid + row0 * 4 * D;
+    TRY(gemm(c, att, D, L.wm, m1, D, rows, D, D, SCREAM_EPI_RES_LN, 0, nullptr, x, L.g1, L.b1));
+    TRY(gemm(c, m1, D, L.w1, hid, 4 * D, rows, 4 * D, D, SCREAM_EPI_RELU, 0, nullptr, nullptr, nullptr, nullptr));
+    TRY(gemm(c, hid, 4 * D, L.w2, y, D, rows, D, 4 * D, SCREAM_EPI_RES_LN, 0, nullptr, x, L.g2, L.b2));
     return 0;
 }
 
 enum { TR_QKV = 5 };
 
-// Self attention over rows [0, rows) whose clouds are [0, n_clouds)  (transformer.py:74-90 with q = k = v).
+// Self attention over packed rows [row0, row0 + rows) whose clouds are [cloud_begin, cloud_begin + n_clouds)
+// (transformer.py:74-90 with q = k = v).  x / y are the full feature buffers (row 0 = packed row 0).
 // The q/k/v projection reduces K^T V in its epilogue, so K' and V never reach HBM.
 int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x,
-             float* y, int64_t rows, int32_t n_clouds) {
+             float* y, int64_t row0, int64_t rows, int32_t cloud_begin, int32_t n_clouds) {
+    const float* xr = x + row0 * D;
+    float* qr = w.q + row0 * D;
+    float* kvp = w.kvp + row0 / SCREAM_ROW_TILE * SCREAM_NHEAD * KV_ELEMS;
     {
         Scope sc(c.tr, TR_QKV, rows, 3 * D, D, c.st);
-        TRY(scream_gemm_qkv_f32(x, D, L.wqkv, w.q, D, rows, 3 * D, D, D, b.tile_cloud, b.cloud_row0, b.cloud_len, 0,
-                                w.kvp, c.st));
+        TRY(scream_gemm_qkv_f32(xr, D, L.wqkv, qr, D, rows, 3 * D, D, D, b.tile_cloud, b.cloud_row0, b.cloud_len, row0,
+                                kvp, c.st));
     }
     {
         Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
-        TRY(scream_kv_finalize(w.kvp, b.cloud_row0, b.cloud_len, 0, 0, n_clouds, w.kv, c.st));
+        TRY(scream_kv_finalize(kvp, b.cloud_row0, b.cloud_len, row0, cloud_begin, n_clouds, w.kv, c.st));
     }
     {
         Scope sc(c.tr, TR_ATTN_APPLY, rows, 0, 0, c.st);
-        TRY(scream_attn_apply(w.q, D, w.kv, b.tile_cloud, 0, b.cloud_len, w.att, D, rows, c.st));
+        TRY(scream_attn_apply(qr, D, w.kv, b.tile_cloud + row0 / SCREAM_ROW_TILE, 0, b.cloud_len, w.att + row0 * D, D, rows,
+                              c.st));
     }
-    return mha_tail(c, L, w, x, y, rows);
+    return mha_tail(c, L, w, xr, y + row0 * D, row0, rows);
 }
 
 // Cross attention: queries from the source rows, keys/values from the frozen target rows (transformer.py:130).
@@ -135,13 +145,13 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
         Scope sc(c.tr, TR_ATTN_APPLY, rs, 0, 0, c.st);
         TRY(scream_attn_apply(w.q, D, w.kv, b.tile_cloud, b.n_pairs, b.cloud_len, w.att, D, rs, c.st));
     }
-    return mha_tail(c, L, w, x_src, y, rs);
+    return mha_tail(c, L, w, x_src, y, 0, rs);
 }
 
 }  // namespace
 
-extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi3"; }
-extern "C" int scream_abi_version(void) { return 3; }
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi4"; }
+extern "C" int scream_abi_version(void) { return 4; }
 
 extern "C" void* scream_trace_create(int32_t capacity) {
     if (capacity <= 0) return nullptr;
@@ -216,8 +226,13 @@ extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t*
     }
     float* cur = w.x0;
     float* nxt = w.x1;
-    for (int i = 0; i < m.n_self; ++i) {  // pointnet.py:50-52
-        TRY(mha_self(c, m.layers_host[i], b, w, cur, nxt, ra, 2 * b.n_pairs));
+    for (int i = 0; i < m.n_self; ++i) {
+        if (!m.stem_tgt_layers_host) {  // pointnet.py:50-52: one set of stem weights for both clouds
+            TRY(mha_self(c, m.layers_host[i], b, w, cur, nxt, 0, ra, 0, 2 * b.n_pairs));
+        } else {  // DEMTransformer (pointnet.py:113-118,143-145): stem_dsm on the first clouds, stem_dem on the second
+            TRY(mha_self(c, m.layers_host[i], b, w, cur, nxt, 0, rs, 0, b.n_pairs));
+            TRY(mha_self(c, m.stem_tgt_layers_host[i], b, w, cur, nxt, rs, ra - rs, b.n_pairs, b.n_pairs));
+        }
         float* t = cur;
         cur = nxt;
         nxt = t;
@@ -226,7 +241,7 @@ extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t*
     for (int i = 0; i < 2 * m.n_cross; ++i) {  // pointnet.py:53-57
         const scream_layer_t& L = m.layers_host[m.n_self + i];
         if (i % 2 == 0) {
-            TRY(mha_self(c, L, b, w, cur, nxt, rs, b.n_pairs));
+            TRY(mha_self(c, L, b, w, cur, nxt, 0, rs, 0, b.n_pairs));
         } else {
             TRY(mha_cross(c, L, b, w, cur, x_tgt, nxt));
         }

@@ -10,7 +10,7 @@ import torch
 from . import _lib, ops
 from .packing import PackedBatch
 
-__all__ = ["square_distance", "nn_search_pair", "rigid_transform_3d", "integrate_trans", "transformation_error",
+__all__ = ["square_distance", "nn_search_pair", "chamfer_distance", "rigid_transform_3d", "integrate_trans", "transformation_error",
            "register_from_prediction", "register_batch", "processbar"]
 
 
@@ -39,6 +39,15 @@ def square_distance(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     _lib.check(_lib.load().scream_square_distance(ops._p(src.contiguous().float()), ops._p(dst.contiguous().float()),
                                                   ops._p(out), B, N, M, ops._stream()), "scream_square_distance")
     return out
+
+
+def chamfer_distance(f: torch.Tensor, f_: torch.Tensor) -> torch.Tensor:
+    """The symmetric squared-distance Chamfer term of evaluate_open_gf.py:25-41 (``ChamferDistance``):
+    mean_n min_m |f_n - f'_m|^2 + mean_m min_n |f'_m - f_n|^2 for ONE pair of clouds [1,N,3], [1,M,3] -- two fused
+    1-NN searches instead of the reference's dense N x M matrix and its two ``min``."""
+    d_ab, _, _ = nn_search_pair(f[0], f_[0], 1.0, float("inf"))
+    d_ba, _, _ = nn_search_pair(f_[0], f[0], 1.0, float("inf"))
+    return d_ab.mean() + d_ba.mean()
 
 
 def integrate_trans(R, t):

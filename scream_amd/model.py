@@ -85,6 +85,9 @@ class PointTransformer(nn.Module):
             mods.append(m if i % 2 == 0 else m.layer)
         return mods
 
+    def _stem_tgt_modules(self) -> Optional[List[_MHAParams]]:
+        return None  # PointTransformer: one stem for both clouds
+
     def _signature(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
@@ -104,8 +107,10 @@ class PointTransformer(nn.Module):
             return t.data_ptr()
 
         mods = self._layer_modules()
+        tgt_mods = self._stem_tgt_modules() or []
         layers = (_lib.LayerT * len(mods))()
-        for L, m in zip(layers, mods):
+        tgt_layers = (_lib.LayerT * max(len(tgt_mods), 1))()
+        for L, m in list(zip(layers, mods)) + list(zip(tgt_layers, tgt_mods)):
             # [q | k heads 0-3 | v heads 0-3 | k heads 4-7 | v heads 4-7]: a 256-wide GEMM tile then holds K and V of
             # four heads for the same tokens, which is what the fused K^T V epilogue needs (include/scream_hip.h)
             k, v = m.k_proj.weight, m.v_proj.weight
@@ -122,10 +127,11 @@ class PointTransformer(nn.Module):
         mt.emb_b = dev_f32(self.embedding.bias)
         mt.pre_g, mt.pre_b = dev_f32(self.pre_norm.weight), dev_f32(self.pre_norm.bias)
         mt.layers_host = C.cast(layers, C.POINTER(_lib.LayerT))
+        mt.stem_tgt_layers_host = C.cast(tgt_layers, C.POINTER(_lib.LayerT)) if tgt_mods else None
         mt.c0_w, mt.c0_b = dev_f32(self.coor_mlp[0].weight[:, :, 0]), dev_f32(self.coor_mlp[0].bias)
         mt.c2_w, mt.c2_b = dev_f32(self.coor_mlp[2].weight[:, :, 0]), dev_f32(self.coor_mlp[2].bias)
         mt.c4_w, mt.c4_b = dev_f32(self.coor_mlp[4].weight[:, :, 0]), dev_f32(self.coor_mlp[4].bias)
-        self._packed = (mt, layers, keep)
+        self._packed = (mt, (layers, tgt_layers), keep)
         self._packed_sig = sig
         return self._packed
 
@@ -181,3 +187,57 @@ class PointTransformer(nn.Module):
         """models/pointnet.py:93-99 (L1 point loss; metric bookkeeping, not a hot-path kernel)."""
         reg = (torch.matmul(rot_gt, src_pcd.permute([0, 2, 1])) + trans_gt).permute([0, 2, 1])
         return torch.mean(torch.sum(torch.abs(src_pred - reg), dim=-1), dim=1).mean(dim=0)
+
+
+class DEMTransformer(PointTransformer):
+    """models/pointnet.py:103-167 (ground generation on OpenGF): the same blocks with separate stem weights for the
+    DSM cloud (``stem_dsm``) and the coarse DEM cloud (``stem_dem``), raw coordinates into the embedding for both
+    clouds, no correspondence/Kabsch stage.  forward(dsm, dem_coarse, get_imgs=False) -> (dem_, imgs)."""
+
+    def __init__(self, d_model: int = 256, self_layer_num: int = 6, cross_layer_num: int = 6):
+        nn.Module.__init__(self)
+        if d_model != D_MODEL:
+            raise NotImplementedError("the gfx950 kernels are built for d_model=256")
+        self.embedding = nn.Conv1d(3, d_model, kernel_size=1, stride=1)
+        self.pre_norm = nn.LayerNorm(d_model)
+        self.self_layer_num = self_layer_num
+        self.cross_layer_num = cross_layer_num
+        self.stem_dsm = nn.ModuleList([_MHAParams(d_model) for _ in range(self_layer_num)])
+        self.stem_dem = nn.ModuleList([_MHAParams(d_model) for _ in range(self_layer_num)])
+        self.cross = nn.ModuleList()
+        for _ in range(cross_layer_num):
+            self.cross.append(_MHAParams(d_model))
+            self.cross.append(_CrossParams(d_model))
+        self.coor_mlp = nn.Sequential(nn.Conv1d(d_model, d_model, 1), nn.ReLU(), nn.Conv1d(d_model, d_model, 1),
+                                      nn.ReLU(), nn.Conv1d(d_model, 3, 1))
+        self._packed = None
+        self._packed_sig = None
+        self._ws = None
+
+    def _layer_modules(self) -> List[_MHAParams]:
+        mods = list(self.stem_dsm)
+        for i, m in enumerate(self.cross):
+            mods.append(m if i % 2 == 0 else m.layer)
+        return mods
+
+    def _stem_tgt_modules(self) -> Optional[List[_MHAParams]]:
+        return list(self.stem_dem)
+
+    @torch.no_grad()
+    def forward(self, dsm, dem_coarse, get_imgs=False):
+        assert dsm.shape[0] == 1, "batch size must 1"
+        assert dem_coarse.shape[0] == 1, "batch size must 1"
+        if get_imgs:
+            raise NotImplementedError("get_imgs=True (depth renderer, models/render.py) is out of scope")
+        zero = torch.zeros(3, device=dsm.device)  # both clouds embed their raw coordinates (pointnet.py:138-139)
+        batch = PackedBatch.from_pairs([dsm[0]], [dem_coarse[0]], [zero])
+        dem_ = self.forward_packed(batch)[: dsm.shape[1]].unsqueeze(0).clone()
+        return dem_, None
+
+    def forward_batch(self, dsms, dems, centers=None):
+        zero = torch.zeros(3, device=dsms[0].device)
+        return super().forward_batch(dsms, dems, [zero] * len(dsms))
+
+    def loss(self, dem_pred, dem):
+        """models/pointnet.py:162-166."""
+        return torch.mean(torch.sum(torch.abs(dem_pred - dem), dim=-1), dim=1).mean(dim=0)

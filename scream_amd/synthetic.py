@@ -49,11 +49,27 @@ def state_dict_keys(d_model: int = 256, n_self: int = 6, n_cross: int = 6):
     return keys
 
 
-def make_state_dict(seed: int, d_model: int = 256, n_self: int = 6, n_cross: int = 6) -> "OrderedDict[str, torch.Tensor]":
+def dem_state_dict_keys(d_model: int = 256, n_self: int = 6, n_cross: int = 6):
+    """(name, shape) of DEMTransformer's state_dict (models/pointnet.py:104-131) in registration order."""
+    d = d_model
+    keys = [("embedding.weight", (d, 3, 1)), ("embedding.bias", (d,)),
+            ("pre_norm.weight", (d,)), ("pre_norm.bias", (d,))]
+    for stem in ("stem_dsm", "stem_dem"):
+        for i in range(n_self):
+            keys += _mha_keys("%s.%d." % (stem, i), d)
+    for i in range(2 * n_cross):
+        keys += _mha_keys("cross.%d." % i if i % 2 == 0 else "cross.%d.layer." % i, d)
+    keys += [("coor_mlp.0.weight", (d, d, 1)), ("coor_mlp.0.bias", (d,)),
+             ("coor_mlp.2.weight", (d, d, 1)), ("coor_mlp.2.bias", (d,)),
+             ("coor_mlp.4.weight", (3, d, 1)), ("coor_mlp.4.bias", (3,))]
+    return keys
+
+
+def make_state_dict(seed: int, d_model: int = 256, n_self: int = 6, n_cross: int = 6, dem: bool = False) -> "OrderedDict[str, torch.Tensor]":
     """Seeded fp32 weights: matrices U(-1/sqrt(fan_in), +), LN gain 1 +- 0.1, LN/conv bias +- 0.1."""
     rng = np.random.default_rng(seed)
     sd = OrderedDict()
-    for name, shape in state_dict_keys(d_model, n_self, n_cross):
+    for name, shape in (dem_state_dict_keys if dem else state_dict_keys)(d_model, n_self, n_cross):
         if "norm" in name and name.endswith("weight"):
             w = 1.0 + 0.1 * rng.uniform(-1, 1, size=shape)
         elif name.endswith("bias"):

@@ -78,6 +78,16 @@ def test_state_dict_layout_matches_reference_names():
     net.load_state_dict(make_state_dict(1, 256, 6, 6), strict=True)
 
 
+def test_dem_transformer_state_dict_layout():
+    from scream_amd.model import DEMTransformer
+    from scream_amd.synthetic import dem_state_dict_keys
+    net = DEMTransformer(256, 2, 1)
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(s)) for k, s in dem_state_dict_keys(256, 2, 1)]
+    net.load_state_dict(make_state_dict(1, 256, 2, 1, dem=True), strict=True)
+    with pytest.raises(_lib.ScreamHipError):
+        net(torch.zeros(1, 5, 3), torch.zeros(1, 5, 3))
+
+
 def test_loss_matches_oracle():
     from scream_amd.model import PointTransformer
     net = PointTransformer(256, 1, 1)

@@ -121,3 +121,13 @@ def test_rmse_metric_real_info(golden):
     assert O.rmse_metric(np.eye(4), info[0]) == 0.0
     er = np.linalg.inv(P[0].astype(np.float64)) @ P[1].astype(np.float64)
     assert O.rmse_metric(er, info[1]) > 0
+
+
+def test_dem_transformer(golden):
+    from scream_amd.synthetic import dem_state_dict_keys
+    g = golden("dem")
+    for seed, ns, nc, n, m in g["cases"]:
+        sd = make_state_dict(int(seed), 256, int(ns), int(nc), dem=True)
+        assert list(sd) == [k for k, _ in dem_state_dict_keys(256, int(ns), int(nc))]
+        out = O.dem_transformer_forward(torch.from_numpy(g["dsm_%d" % seed]), torch.from_numpy(g["dem_%d" % seed]), sd)
+        np.testing.assert_allclose(out.numpy(), g["out_%d" % seed], rtol=1e-4, atol=2e-5)
