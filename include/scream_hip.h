@@ -75,6 +75,19 @@ int scream_gemm_qkv_f32(const float* A, int64_t lda, const float* W, float* Q, i
 int scream_kv_finalize(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
                        int64_t row_base, int32_t cloud_begin, int32_t n_kv, float* kv_out, void* stream);
 
+/* ---- The same two GEMM entry points on the bf16 matrix cores with 3-way operand splitting (fp32-level accuracy:
+ * x = x0 + x1 + x2 in bf16, six bf16 MFMAs per 16-deep step, fp32 accumulate; scream_amd/csrc/gemm_x3.hip).
+ * W_planes is the weight matrix pre-split on the host: [3][N][K] bf16 (plane p of W: p0 = bf16(W),
+ * p1 = bf16(W - p0), p2 = bf16(W - p0 - p1)); A, C, residual, bias stay fp32.  M % 128 == 0. */
+int scream_gemm_x3_f32(const float* A, int64_t lda, const void* W_planes, float* C, int64_t ldc, int64_t M,
+                       int32_t N, int32_t K, int32_t epilogue, int32_t n_act, const float* bias,
+                       const float* residual, int64_t ldr, const float* gamma, const float* beta,
+                       void* stream);
+int scream_gemm_qkv_x3_f32(const float* A, int64_t lda, const void* W_planes, float* Q, int64_t ldq,
+                           int64_t M, int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
+                           const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
+                           float* kv_partial, void* stream);
+
 /* ---- A1: feats = LayerNorm(PE_sine(xyz) + W_e (xyz - center[cloud]) + b_e)
  * Replaces models/pointnet.py:45-48 (+ models/transformer.py:157-179).  xyz [rows,3] packed;
  * tile_cloud[rows/128] gives the cloud of each 128-row tile; center [n_clouds,3] (zeros for

@@ -16,6 +16,7 @@ ARCH = "gfx950"
 # parity-critical files keep every fp32 operation individually rounded (see the file headers)
 SOURCES = {
     "gemm_f32.hip": [],
+    "gemm_x3.hip": [],
     "embed.hip": [],
     "attention.hip": [],
     "forward.hip": [],

@@ -30,7 +30,7 @@
 //   cycles, s_memtime stamps in profiles/r01_gemm_stamps.txt) sits on the critical path any more.
 //   Tiles are numbered so that the N-tiles of one M-tile run back to back on ONE XCD (shared A
 //   rows in that XCD's L2) -- placement only changes speed, never results.
-#include "common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -38,32 +38,6 @@ constexpr int BM = 128;
 constexpr int BN = 256;
 constexpr int THREADS = 256;
 constexpr int MAX_GRID = 512;   // 256 CUs x 2 resident blocks
-
-struct EpiArgs {
-    int n_act;
-    const float* bias;
-    const float* residual;
-    int64_t ldr;
-    const float* gamma;
-    const float* beta;
-    // SCREAM_EPI_QKV only
-    float* kv_partial;          // [M/128][8][33*32]
-    const int32_t* tile_cloud;  // cloud of each 128-row tile of the packed batch
-    const int32_t* cloud_row0;
-    const int32_t* cloud_len;
-    int64_t row_base;           // packed row of A's row 0
-};
-
-constexpr int KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;
-
-__device__ __forceinline__ void lds_barrier() {
-    // workgroup barrier that waits for this wave's LDS traffic only: a __syncthreads() would also drain the
-    // LDS-DMA prefetch of the next tile that is deliberately left in flight (vmcnt).
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
-}
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -208,128 +182,8 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_f32_kernel(const float* __res
         }
 
         __builtin_amdgcn_s_setprio(2);  // the epilogue's LDS/VALU/store issue is otherwise starved by the partner block's MFMA stream
-        // ---- fused K^T V epilogue (SCREAM_EPI_QKV, key/value tiles) ------------------------------------------------
-        // A key/value tile holds, for four heads, K (columns 0-127) and V (columns 128-255) of the same 128 tokens.
-        // In the 32x32 accumulator layout lane = column and the registers walk the rows, which is exactly the A / B
-        // operand layout of v_mfma_f32_32x32x2_f32 with the TOKEN as the contraction index: KV_h += mfma(K'_h[e], V_h[e])
-        // over the 16 accumulator registers is sum_tokens K'[t,d] V[t,v] -- straight from registers, K' and V never
-        // reach HBM (models/transformer.py:38-41: the "nshd,nshv->nhdv" einsum and K.sum; the division by v_length, which
-        // the reference applies to V "to prevent fp16 overflow", is linear and is applied to the fp32 sum in scream_kv_finalize).
-        if (EPI == SCREAM_EPI_QKV && n0_cur >= ep.n_act) {
-            const int mt_local = (int)(m0_cur / BM);
-            const int cloud = ep.tile_cloud[(ep.row_base + m0_cur) / BM];
-            const int clen = ep.cloud_len[cloud];
-            const int valid_w = clen - (int)(ep.row_base + m0_cur - ep.cloud_row0[cloud]) - wave * 32;  // real tokens in this wave's rows
-            const int hb = (n0_cur - ep.n_act) / BN * 4;
-            float* part = ep.kv_partial + ((int64_t)mt_local * SCREAM_NHEAD + hb) * KV_ELEMS;
-            float* slabs = smem + WTILE;  // 2 heads x 4 waves x 1056 floats: the free W buffer plus the 1 KiB tail
-#pragma unroll
-            for (int hp = 0; hp < 2; ++hp) {  // two heads per round: 4 workgroup barriers per tile instead of 8
-#pragma unroll
-                for (int hh2 = 0; hh2 < 2; ++hh2) {
-                    const int hq = hp * 2 + hh2;
-                    f32x16 kv;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) kv[e] = 0.f;
-                    float ks = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float a = acc[hq][e];
-                        a = a > 0.f ? a + 1.0f : expf(a);                  // elu(k) + 1
-                        if (mfma32_row(e, half) >= valid_w) a = 0.f;       // padding rows do not exist
-                        kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[4 + hq][e], kv, 0, 0, 0);  // (1 / v_length is applied once, in scream_kv_finalize)
-                        ks += a;
-                    }
-                    ks += __shfl_xor(ks, 32);
-                    float* sw = slabs + (hh2 * 4 + wave) * KV_ELEMS;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) sw[mfma32_row(e, half) * 32 + r] = kv[e];  // [d][v]
-                    if (half == 0) sw[32 * 32 + r] = ks;
-                }
-                lds_barrier();
-                for (int i = tid; i < 2 * KV_ELEMS; i += THREADS) {
-                    const int hh2 = i >= KV_ELEMS ? 1 : 0, k = i - hh2 * KV_ELEMS;
-                    const float* s4 = slabs + hh2 * 4 * KV_ELEMS + k;
-                    part[(hp * 2 + hh2) * KV_ELEMS + k] = (s4[0] + s4[KV_ELEMS]) + (s4[2 * KV_ELEMS] + s4[3 * KV_ELEMS]);
-                }
-                lds_barrier();
-            }
-        } else {
-        // ---- epilogue (wave-private) ---------------------------------------------------------------------------
-        // acc[tn][e]: row = wave*32 + mfma32_row(e, half), col = tn*32 + r.  The k-loop ended on a barrier and its
-        // last k-tile used buffer 0's partner, so buffer 1 is free: each wave takes an 8-row slab of it.
-        constexpr int SLAB_LD = 256;
-        float* slab = smem + WTILE + wave * (8 * SLAB_LD);
-        const int col = n0_cur + lane * 4;
-        f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};  // bias | gamma, beta
-        if (EPI == SCREAM_EPI_BIAS_RELU) p0 = ld4(ep.bias + col);
-        if (EPI == SCREAM_EPI_RES_LN) {
-            p0 = ld4(ep.gamma + col);
-            p1 = ld4(ep.beta + col);
-        }
-        const bool act = n0_cur < ep.n_act;  // n_act is a multiple of 256: uniform per tile
-        // RES_LN: the residual rows of half-chunk h+1 are requested before half-chunk h is processed, so their
-        // ~2 us first-touch latency is not paid eight times in a row
-        f32x4 rsd[2][4];
-        if (EPI == SCREAM_EPI_RES_LN) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rsd[0][i] = ld4(ep.residual + (m0_cur + wave * 32 + i) * ep.ldr + col);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {  // rows 8g .. 8g+7 of the wave's 32
-#pragma unroll
-            for (int tn = 0; tn < 8; ++tn)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) slab[(i + 4 * half) * SLAB_LD + tn * 32 + r] = acc[tn][4 * g + i];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {  // two halves of 4 rows: keeps the live set inside 256 VGPRs
-                f32x4 vv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) vv[i] = ld4(slab + (hh * 4 + i) * SLAB_LD + lane * 4);
-                const int64_t row0 = m0_cur + wave * 32 + 8 * g + 4 * hh;
-                if (EPI == SCREAM_EPI_RES_LN) {
-                    const int hcur = (2 * g + hh) & 1;
-                    if (2 * g + hh + 1 < 8) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) rsd[hcur ^ 1][i] = ld4(ep.residual + (row0 + 4 + i) * ep.ldr + col);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        vv[i] += rsd[hcur][i];
-                        const float mean = wave_sum((vv[i][0] + vv[i][1]) + (vv[i][2] + vv[i][3])) * (1.0f / 256.0f);
-                        const f32x4 d = vv[i] - mean;
-                        const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 256.0f);
-                        const float rstd = 1.0f / sqrtf(var + 1e-5f);
-                        vv[i] = d * rstd * p0 + p1;
-                    }
-                } else if (EPI == SCREAM_EPI_ELU1 || EPI == SCREAM_EPI_QKV) {
-                    if (act) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) vv[i][c] = vv[i][c] > 0.f ? vv[i][c] + 1.0f : expf(vv[i][c]);  // elu(x)+1 == exp(x), x <= 0
-                    }
-                } else if (EPI == SCREAM_EPI_RELU) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) vv[i][c] = fmaxf(vv[i][c], 0.f);
-                } else if (EPI == SCREAM_EPI_BIAS_RELU) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) vv[i][c] = fmaxf(vv[i][c] + p0[c], 0.f);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(C + (row0 + i) * ldc + col) = vv[i];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        }  // standard epilogue
+        // buffer 1 (+ the 1 KiB tail) is free after the k-loop's last barrier: epilogue scratch
+        gemm_epilogue<EPI, 4>(acc, smem + WTILE, wave, lane, tid, true, m0_cur, n0_cur, ep, C, ldc);
         __builtin_amdgcn_s_setprio(0);
         if (!has_next) break;
         v = v_next;

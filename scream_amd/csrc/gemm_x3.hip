@@ -1,0 +1,240 @@
+// fp32-accurate GEMM  C[M,N] = epilogue(A[M,K] . W[N,K]^T)  on the gfx950 bf16 matrix cores by 3-way operand splitting.
+//
+//   x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)     (exact: 3 x 8 significand bits = fp32)
+//   a.b ~= a2b0 + a1b1 + a0b2 + a1b0 + a0b1 + a0b0                                  (dropped terms <= 2^-24 relative)
+//
+// Every bf16 x bf16 product is exact in fp32 and the six v_mfma_f32_32x32x16_bf16 of a 16-deep step accumulate in
+// fp32, so the result carries fp32-level error -- measured against fp64 it is slightly MORE accurate than the
+// fp32-input MFMA path (max |err| / sum|a||b|: 2.0e-7 vs 2.6e-7 at K = 256, 2.8e-7 vs 3.4e-7 at K = 1024,
+// tools/x3_bench.py) -- while the matrix pipe spends 6 x 32 = 192 cycles per 32x32x16 block instead of 8 x 64 = 512.
+// Same inputs, same outputs, same epilogues and tolerances as gemm_f32.hip; the dtype of the path stays fp32.
+//
+// Geometry: block tile 256 x 256, 512 threads = 8 waves stacked in M (wave tile 32 x 256, 128 accumulator VGPRs), one
+// persistent block per CU.  W is pre-split on the host into three bf16 planes [3][N][K] and staged by LDS-DMA, 32-deep
+// k-tiles, double buffered (2 x 48 KiB; rows are 64 B, 16-byte chunk c of row n lives at c ^ ((n >> 2) & 3) so that
+// the 16 lanes of a ds_read_b128 group cover 16 distinct bank slots).  A stays fp32 in HBM: lane (r, half) streams its
+// 64 contiguous bytes of row r per k-tile straight into registers and splits them there (v_cvt_pk_bf16_f32 + 2 subs per
+// plane).  Lane-half h owns k = 16h + 8s + j of step s for both operands.  A dedicated 64 KiB LDS region holds the
+// epilogue slabs, so the first k-tile of the next output tile is already in flight during the epilogue.
+#include "gemm_epilogue.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int XBM = 256, XBN = 256, XBK = 32, XTHREADS = 512, XWAVES = 8;
+constexpr int PLANE_BYTES = XBN * XBK * 2;     // 16 KiB
+constexpr int STAGE_BYTES = 3 * PLANE_BYTES;   // 48 KiB
+constexpr int SLAB_BYTES = XWAVES * 8 * 256 * 4;  // 64 KiB
+constexpr int X_MAX_GRID = 256;
+
+__device__ __forceinline__ void split3(const f32x4 lo, const f32x4 hi, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float x = i < 4 ? lo[i] : hi[i - 4];
+        const __bf16 a = (__bf16)x;
+        const float r1 = x - (float)a;
+        const __bf16 b = (__bf16)r1;
+        p0[i] = a;
+        p1[i] = b;
+        p2[i] = (__bf16)(r1 - (float)b);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __restrict__ A, int64_t lda,
+                                                             const __bf16* __restrict__ Wp, float* __restrict__ C,
+                                                             int64_t ldc, int64_t M, int n_tiles, unsigned total_tiles,
+                                                             int N, int K, EpiArgs ep) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + SLAB_BYTES];  // 160 KiB
+    float* slabs = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, half = lane >> 5;
+
+    const unsigned q8 = total_tiles >> 3, rem = total_tiles & 7u;
+    auto tile_of = [&](unsigned v) {  // XCD-aware numbering, as in gemm_f32.hip
+        const unsigned xcd = v & 7u;
+        return (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (v >> 3);
+    };
+    // DMA: 48 one-KiB pieces per k-tile (3 planes x 16 pieces of 16 rows x 64 B), six per wave.  Piece id -> (plane,
+    // q) is wave-uniform; the per-lane part (row q*16 + lane/4, source chunk (lane&3) ^ ((row>>2)&3) = (lane&3) ^
+    // ((lane>>4)&3)) does not depend on the piece, so one per-lane base pointer serves all six.
+    const __bf16* w_lane = Wp + (int64_t)(lane >> 2) * K + (((lane & 3) ^ ((lane >> 4) & 3)) << 3);
+    auto dma_w = [&](int n0, int stage, int kt) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int id = wave * 6 + u, plane = id >> 4, q = id & 15;
+            const int64_t soff = ((int64_t)plane * N + n0 + q * 16) * K + kt * XBK;  // scalar
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_lane + soff),
+                                             (lptr_t)(smem + stage * STAGE_BYTES + plane * PLANE_BYTES + q * 1024), 16, 0, 0);
+        }
+    };
+    // A: rows past M (a trailing 128-row half tile) are clamped to the tile's first row and never stored
+    auto a_ptr = [&](int64_t m0, bool ok) { return A + (ok ? m0 + wave * 32 + r : m0) * lda + half * 16; };
+    int boff[2];  // byte offset of this lane's 16-byte chunk of row r for step s (swizzled)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) boff[s] = r * 64 + (((2 * half + s) ^ ((r >> 2) & 3)) << 4);
+
+    const int KT = K / XBK;  // even (host check)
+    unsigned v = blockIdx.x;
+    unsigned tile = tile_of(v);
+    int64_t m0 = (int64_t)(tile / n_tiles) * XBM;
+    int n0 = (int)(tile % n_tiles) * XBN;
+    bool rows_ok = m0 + wave * 32 < M;
+    const float* ga = a_ptr(m0, rows_ok);
+
+    f32x4 a0[4], a1[4];
+    dma_w(n0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a0[j] = ld4(ga + j * 4);
+    __syncthreads();
+
+    for (;;) {
+        f32x16 acc[8];
+#pragma unroll
+        for (int tn = 0; tn < 8; ++tn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[tn][e] = 0.f;
+
+        auto step = [&](int kt, int stage, f32x4 (&ac)[4], f32x4 (&an)[4]) {
+            // retire this k-tile's A loads before anything younger is issued (see gemm_f32.hip)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(ac[j]));
+            if (kt + 1 < KT) {
+                dma_w(n0, stage ^ 1, kt + 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) an[j] = ld4(ga + (kt + 1) * XBK + j * 4);
+            }
+            const char* wb = smem + stage * STAGE_BYTES;
+            bf16x8 fb[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[0][p] = *reinterpret_cast<const bf16x8*>(wb + p * PLANE_BYTES + boff[0]);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pa0, pa1, pa2;
+                split3(ac[2 * s], ac[2 * s + 1], pa0, pa1, pa2);
+#pragma unroll
+                for (int tn = 0; tn < 8; ++tn) {
+                    const int cur = tn & 1, nxt = cur ^ 1;
+                    if (s * 8 + tn + 1 < 16) {  // fragments of the next (step, N-tile) are requested one group ahead
+                        const int s2 = (s * 8 + tn + 1) >> 3, t2 = (s * 8 + tn + 1) & 7;
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            fb[nxt][p] = *reinterpret_cast<const bf16x8*>(wb + p * PLANE_BYTES + t2 * 32 * 64 + boff[s2]);
+                    }
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa2, fb[cur][0], acc[tn], 0, 0, 0);
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, fb[cur][1], acc[tn], 0, 0, 0);
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, fb[cur][2], acc[tn], 0, 0, 0);
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, fb[cur][0], acc[tn], 0, 0, 0);
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, fb[cur][1], acc[tn], 0, 0, 0);
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, fb[cur][0], acc[tn], 0, 0, 0);
+                    // first MFMA, then the three prefetch reads, then the other five MFMAs (hipcc emits lgkmcnt(0)
+                    // rather than a counted wait while an LDS-DMA is in flight)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();  // all reads of `stage` done; k-tile kt+1 landed (vmcnt(0) drained by the barrier's fence)
+        };
+        for (int kt = 0; kt < KT; kt += 2) {
+            step(kt, 0, a0, a1);
+            step(kt + 1, 1, a1, a0);
+        }
+
+        // next output tile: its first k-tile lands under the epilogue (the slabs have their own LDS region)
+        const unsigned v_next = v + gridDim.x;
+        const bool has_next = v_next < total_tiles;
+        const int64_t m0_cur = m0;
+        const int n0_cur = n0;
+        const bool rows_cur = rows_ok;
+        if (has_next) {
+            tile = tile_of(v_next);
+            m0 = (int64_t)(tile / n_tiles) * XBM;
+            n0 = (int)(tile % n_tiles) * XBN;
+            rows_ok = m0 + wave * 32 < M;
+            ga = a_ptr(m0, rows_ok);
+        }
+        if (EPI != SCREAM_EPI_RES_LN && has_next) {
+            dma_w(n0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a0[j] = ld4(ga + j * 4);
+        }
+        gemm_epilogue<EPI, XWAVES>(acc, slabs, wave, lane, tid, rows_cur, m0_cur, n0_cur, ep, C, ldc);
+        if (!has_next) break;
+        v = v_next;
+        if (EPI == SCREAM_EPI_RES_LN) {
+            dma_w(n0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a0[j] = ld4(ga + j * 4);
+        }
+        __syncthreads();
+    }
+}
+
+template <int EPI>
+int launch_x3(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, int64_t M, int N, int K,
+              const EpiArgs& ep, hipStream_t st) {
+    const int n_tiles = N / XBN;
+    const int64_t total = ((M + XBM - 1) / XBM) * n_tiles;
+    if (total == 0) return 0;
+    SCREAM_REQUIRE(total < (1ll << 31), SCREAM_EUNSUPPORTED);
+    const unsigned grid = total < X_MAX_GRID ? (unsigned)total : (unsigned)X_MAX_GRID;
+    gemm_x3_kernel<EPI><<<dim3(grid), dim3(XTHREADS), 0, st>>>(A, lda, reinterpret_cast<const __bf16*>(Wp), C, ldc, M,
+                                                               n_tiles, (unsigned)total, N, K, ep);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int scream_gemm_x3_f32(const float* A, int64_t lda, const void* W_planes, float* C, int64_t ldc, int64_t M,
+                                  int32_t N, int32_t K, int32_t epilogue, int32_t n_act, const float* bias,
+                                  const float* residual, int64_t ldr, const float* gamma, const float* beta,
+                                  void* stream) {
+    SCREAM_REQUIRE(A && W_planes && C, SCREAM_EINVAL);
+    SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K > 0 && K % 64 == 0, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0 && ldc % 4 == 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W_planes) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(C) & 15) == 0, SCREAM_EINVAL);
+    EpiArgs ep{n_act, bias, residual, ldr, gamma, beta, nullptr, nullptr, nullptr, nullptr, 0};
+    hipStream_t st = as_stream(stream);
+    switch (epilogue) {
+        case SCREAM_EPI_NONE:
+            return launch_x3<SCREAM_EPI_NONE>(A, lda, W_planes, C, ldc, M, N, K, ep, st);
+        case SCREAM_EPI_ELU1:
+            SCREAM_REQUIRE(n_act >= 0 && n_act % XBN == 0, SCREAM_EUNSUPPORTED);
+            return launch_x3<SCREAM_EPI_ELU1>(A, lda, W_planes, C, ldc, M, N, K, ep, st);
+        case SCREAM_EPI_RELU:
+            return launch_x3<SCREAM_EPI_RELU>(A, lda, W_planes, C, ldc, M, N, K, ep, st);
+        case SCREAM_EPI_BIAS_RELU:
+            SCREAM_REQUIRE(bias, SCREAM_EINVAL);
+            return launch_x3<SCREAM_EPI_BIAS_RELU>(A, lda, W_planes, C, ldc, M, N, K, ep, st);
+        case SCREAM_EPI_RES_LN:
+            SCREAM_REQUIRE(N == XBN, SCREAM_EUNSUPPORTED);
+            SCREAM_REQUIRE(residual && gamma && beta && ldr >= N && ldr % 4 == 0, SCREAM_EINVAL);
+            SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(residual) & 15) == 0, SCREAM_EINVAL);
+            return launch_x3<SCREAM_EPI_RES_LN>(A, lda, W_planes, C, ldc, M, N, K, ep, st);
+        default:
+            return SCREAM_EINVAL;
+    }
+}
+
+extern "C" int scream_gemm_qkv_x3_f32(const float* A, int64_t lda, const void* W_planes, float* Q, int64_t ldq, int64_t M,
+                                      int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
+                                      const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
+                                      float* kv_partial, void* stream) {
+    SCREAM_REQUIRE(A && W_planes && kv_partial && tile_cloud && cloud_row0 && cloud_len, SCREAM_EINVAL);
+    SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K > 0 && K % 64 == 0, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE((n_q == 0 || n_q == XBN) && N == n_q + 2 * XBN && row_base >= 0 && row_base % SCREAM_ROW_TILE == 0,
+                   SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE(n_q == 0 || (Q && ldq >= n_q && ldq % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0), SCREAM_EINVAL);
+    SCREAM_REQUIRE(lda >= K && lda % 4 == 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W_planes) & 15) == 0, SCREAM_EINVAL);
+    EpiArgs ep{n_q, nullptr, nullptr, 0, nullptr, nullptr, kv_partial, tile_cloud, cloud_row0, cloud_len, row_base};
+    return launch_x3<SCREAM_EPI_QKV>(A, lda, W_planes, Q, ldq, M, N, K, ep, as_stream(stream));
+}

@@ -52,15 +52,46 @@ def gemm_f32(A: torch.Tensor, W: torch.Tensor, epilogue: int = EPI_NONE, n_act: 
     return out
 
 
+def split_planes(W: torch.Tensor) -> torch.Tensor:
+    """[N,K] fp32 -> [3,N,K] bf16 planes with p0 + p1 + p2 == W exactly (weight repacking for the x3 GEMMs)."""
+    W = W.detach().float()
+    p0 = W.to(torch.bfloat16)
+    r1 = W - p0.float()
+    p1 = r1.to(torch.bfloat16)
+    p2 = (r1 - p1.float()).to(torch.bfloat16)
+    return torch.stack([p0, p1, p2]).contiguous()
+
+
+def gemm_x3(A: torch.Tensor, Wp: torch.Tensor, epilogue: int = EPI_NONE, n_act: int = 0,
+            bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+            gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gemm_f32's contract on the bf16 matrix cores (3-way split, fp32-level accuracy); Wp = split_planes(W)."""
+    M, K = A.shape
+    N = Wp.shape[1]
+    assert Wp.shape == (3, N, K) and Wp.dtype == torch.bfloat16
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    check(_lib.load().scream_gemm_x3_f32(_p(A), A.stride(0), _p(Wp, torch.bfloat16), _p(out), out.stride(0), M, N, K,
+                                         epilogue, n_act, _p(bias), _p(residual),
+                                         residual.stride(0) if residual is not None else 0, _p(gamma), _p(beta), _stream()),
+          "scream_gemm_x3_f32")
+    return out
+
+
 def gemm_qkv(A: torch.Tensor, W: torch.Tensor, n_q: int, tile_cloud, cloud_row0, cloud_len, row_base: int):
     """Fused q/k/v projection (scream_gemm_qkv_f32).  Returns (Q' [M,256] or None, kv_partial [M/128,8,1056])."""
     M, K = A.shape
     N = W.shape[0]
+    x3 = W.dim() == 3  # [3,N,K] bf16 planes -> the split kernel
+    if x3:
+        N = W.shape[1]
     Q = torch.empty(M, n_q, device=A.device, dtype=torch.float32) if n_q else None
     part = torch.empty(M // ROW_TILE, 8, KV_ELEMS, device=A.device, dtype=torch.float32)
-    check(_lib.load().scream_gemm_qkv_f32(_p(A), A.stride(0), _p(W), _p(Q), n_q, M, N, K, n_q,
-                                          _p(tile_cloud, torch.int32), _p(cloud_row0, torch.int32),
-                                          _p(cloud_len, torch.int32), row_base, _p(part), _stream()), "scream_gemm_qkv_f32")
+    fn = _lib.load().scream_gemm_qkv_x3_f32 if x3 else _lib.load().scream_gemm_qkv_f32
+    check(fn(_p(A), A.stride(0), _p(W, torch.bfloat16 if x3 else torch.float32), _p(Q), n_q, M, N, K, n_q,
+             _p(tile_cloud, torch.int32), _p(cloud_row0, torch.int32), _p(cloud_len, torch.int32), row_base, _p(part),
+             _stream()), "scream_gemm_qkv")
     return Q, part
 
 

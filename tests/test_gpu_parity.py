@@ -31,38 +31,47 @@ def build_net(seed, n_self, n_cross):
 
 
 # ------------------------------------------------------------------------------------- GEMM
+def _gemm(kind, A, W, *a, **k):
+    """The same GEMM contract on both matrix-core paths: fp32-input MFMA and 3 x bf16 split."""
+    return ops.gemm_f32(A, W, *a, **k) if kind == "f32" else ops.gemm_x3(A, ops.split_planes(W), *a, **k)
+
+
+@pytest.mark.parametrize("kind", ["f32", "x3"])
 @pytest.mark.parametrize("M,N,K", [(128, 256, 256), (384, 768, 256), (256, 1024, 256), (256, 256, 1024), (128, 512, 64), (66048, 256, 256)])
-def test_gemm_plain_and_activations(M, N, K):
+def test_gemm_plain_and_activations(M, N, K, kind):
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)
     W = torch.randn(N, K, generator=g) / K ** 0.5
     ref = (A.double() @ W.double().t())
-    out = ops.gemm_f32(dev(A), dev(W)).cpu()
+    out = _gemm(kind, dev(A), dev(W)).cpu()
     torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=2e-5)
-    out = ops.gemm_f32(dev(A), dev(W), ops.EPI_RELU).cpu()
+    out = _gemm(kind, dev(A), dev(W), ops.EPI_RELU).cpu()
     torch.testing.assert_close(out.double(), ref.clamp_min(0), rtol=1e-5, atol=2e-5)
     if N >= 512:
-        out = ops.gemm_f32(dev(A), dev(W), ops.EPI_ELU1, n_act=N - 256).cpu()
+        out = _gemm(kind, dev(A), dev(W), ops.EPI_ELU1, n_act=N - 256).cpu()
         want = ref.clone()
         want[:, : N - 256] = torch.nn.functional.elu(ref[:, : N - 256]) + 1
         torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=2e-5)
     bias = torch.randn(N, generator=g)
-    out = ops.gemm_f32(dev(A), dev(W), ops.EPI_BIAS_RELU, bias=dev(bias)).cpu()
+    out = _gemm(kind, dev(A), dev(W), ops.EPI_BIAS_RELU, bias=dev(bias)).cpu()
     torch.testing.assert_close(out.double(), (ref + bias.double()).clamp_min(0), rtol=1e-5, atol=2e-5)
 
 
-def test_gemm_asymmetric_identity():
-    """A = I with an asymmetric W catches a transposed fragment/C map (cdna guide, section 3)."""
+@pytest.mark.parametrize("kind", ["f32", "x3"])
+def test_gemm_asymmetric_identity(kind):
+    """A = I with an asymmetric W catches a transposed fragment/C map (cdna guide, section 3); exact on both paths
+    (the 3-way bf16 split of W is exact and 1.0 x w needs no rounding)."""
     K = N = 256
     A = torch.zeros(128, K)
     A[torch.arange(128), torch.arange(128)] = 1.0
     W = torch.arange(N * K, dtype=torch.float32).reshape(N, K) / 1000.0
-    out = ops.gemm_f32(dev(A), dev(W)).cpu()
+    out = _gemm(kind, dev(A), dev(W)).cpu()
     torch.testing.assert_close(out, W.t()[:128].contiguous(), rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("kind", ["f32", "x3"])
 @pytest.mark.parametrize("K", [256, 1024])
-def test_gemm_residual_layernorm(K):
+def test_gemm_residual_layernorm(K, kind):
     g = torch.Generator().manual_seed(K)
     M, N = 256, 256
     A = torch.randn(M, K, generator=g)
@@ -70,7 +79,7 @@ def test_gemm_residual_layernorm(K):
     res = torch.randn(M, N, generator=g)
     gamma, beta = 1 + 0.1 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
     want = torch.nn.functional.layer_norm((A.double() @ W.double().t()) + res.double(), (N,), gamma.double(), beta.double(), 1e-5)
-    out = ops.gemm_f32(dev(A), dev(W), ops.EPI_RES_LN, residual=dev(res), gamma=dev(gamma), beta=dev(beta)).cpu()
+    out = _gemm(kind, dev(A), dev(W), ops.EPI_RES_LN, residual=dev(res), gamma=dev(gamma), beta=dev(beta)).cpu()
     torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=2e-5)
 
 
@@ -136,7 +145,8 @@ def test_kv_reduce_multichunk_vs_oracle():
     torch.testing.assert_close(kv[0, :, 32 * 32:], want["Ksum"][0], rtol=1e-5, atol=1e-4)
 
 
-def test_fused_qkv_projection_and_kv_reduce_vs_oracle():
+@pytest.mark.parametrize("kind", ["f32", "x3"])
+def test_fused_qkv_projection_and_kv_reduce_vs_oracle(kind):
     """scream_gemm_qkv_f32 + scream_kv_finalize: Q' = elu(x Wq^T)+1 stored, K^T (V/S) and Ksum reduced from the
     accumulators per cloud -- against the oracle's intermediates, two ragged clouds incl. padding rows."""
     sd = make_state_dict(9, 256, 1, 1)
@@ -153,7 +163,8 @@ def test_fused_qkv_projection_and_kv_reduce_vs_oracle():
     W = torch.cat([q, k[:128], v[:128], k[128:], v[128:]], dim=0)
     tile_cloud = dev(torch.tensor([0, 0, 0, 1, 1], dtype=torch.int32))
     crow0, clen = dev(torch.tensor(row0, dtype=torch.int32)), dev(torch.tensor(lens, dtype=torch.int32))
-    Q, part = ops.gemm_qkv(dev(x), dev(W), 256, tile_cloud, crow0, clen, 0)
+    pack = (lambda w: dev(w)) if kind == "f32" else (lambda w: ops.split_planes(dev(w)))
+    Q, part = ops.gemm_qkv(dev(x), pack(W), 256, tile_cloud, crow0, clen, 0)
     kv = ops.kv_finalize(part, crow0, clen, 0, 0, 2, 2).cpu()
     for ci, (r0, xc) in enumerate(zip(row0, xs)):
         want = {}
@@ -165,7 +176,7 @@ def test_fused_qkv_projection_and_kv_reduce_vs_oracle():
         torch.testing.assert_close(kv[ci, :, 1024:], want["Ksum"][0], rtol=1e-5, atol=1e-4)
     # key/value-only form used by the cross layers (n_q = 0, rows offset by row_base)
     Wkv = W[256:].contiguous()
-    _, part2 = ops.gemm_qkv(dev(x[384:]), dev(Wkv), 0, tile_cloud, crow0, clen, 384)
+    _, part2 = ops.gemm_qkv(dev(x[384:]), pack(Wkv), 0, tile_cloud, crow0, clen, 384)
     kv2 = ops.kv_finalize(part2, crow0, clen, 384, 1, 1, 2).cpu()
     torch.testing.assert_close(kv2[1], kv[1], rtol=0, atol=0)
 
