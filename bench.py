@@ -9,11 +9,13 @@ in HBM: PointTransformer forward -> thresholded 1-NN -> fused gather + Kabsch ->
 of per-pair metric rows when N > 1, the path's only collective).  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline     -- the fp32-MFMA GEMM kernel (all epilogue instantiations pooled; per-instantiation rows in
-                  "by_kernel" so they can be matched against profiles/*kernel_stats*): algorithmic flops
-                  (true, unpadded token counts) / summed launch time, measured live with HIP events on the
-                  launch stream inside the timed region (scream_trace_*), against the 157.3 TFLOP/s fp32
-                  matrix peak of MI355X_MICROARCH.md.
+  roofline     -- the GEMM kernel (all epilogue instantiations pooled; per-instantiation rows in "by_kernel" so
+                  they can be matched against profiles/*kernel_stats*): algorithmic fp32 flops (true, unpadded
+                  token counts) / summed launch time, measured live with HIP events on the launch stream inside
+                  the timed region (scream_trace_*).  Peak (MI355X_MICROARCH.md): SCREAM_GEMM=x3 (default) runs
+                  gemm_x3_kernel on the bf16 matrix cores with six MFMAs per fp32 product -> 2500 / 6 = 416.7
+                  TFLOP/s of fp32-equivalent work; SCREAM_GEMM=f32 runs gemm_f32_kernel against the 157.3
+                  TFLOP/s fp32 matrix peak.
   cpu_baseline -- the CPU oracle (oracle/scream_ref.py, a PyTorch-CPU restatement validated against the
                   reference) on a bounded sample of the same pairs, on this box's host cores.
 """
@@ -31,10 +33,11 @@ sys.path.insert(0, REPO)
 
 PAIRS_PER_GPU = 32
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
-GEMM_NAMES = {0: "gemm_f32_kernel<EPI_NONE>", 1: "gemm_f32_kernel<EPI_ELU1> (cross-layer q projection)",
-              5: "gemm_f32_kernel<EPI_QKV> (q/k/v projection + fused K^T V reduce)",
-              2: "gemm_f32_kernel<EPI_RELU> (FFN 256->1024)", 3: "gemm_f32_kernel<EPI_BIAS_RELU> (coor_mlp)",
-              4: "gemm_f32_kernel<EPI_RES_LN> (merge, FFN 1024->256 + residual + LayerNorm)",
+PEAK_BF16_DENSE_TFLOPS = 2500.0  # same table; the split GEMM spends six bf16 MFMAs per fp32 product
+GEMM_NAMES = {0: "gemm<EPI_NONE>", 1: "gemm<EPI_ELU1> (cross-layer q projection)",
+              5: "gemm<EPI_QKV> (q/k/v projection + fused K^T V reduce)",
+              2: "gemm<EPI_RELU> (FFN 256->1024)", 3: "gemm<EPI_BIAS_RELU> (coor_mlp)",
+              4: "gemm<EPI_RES_LN> (merge, FFN 1024->256 + residual + LayerNorm)",
               100: "pe_embed_ln_kernel", 101: "kv_finalize_tiles_kernel", 102: "attn_apply_kernel",
               103: "coor_head_kernel"}
 
@@ -220,6 +223,13 @@ def main():
                       "tflops_padded": round(2.0 * k_[1] * k_[2] * k_[3] / (v["ms"] / v["launches"] * 1e-3) / 1e12, 1)}
                      for k_, v in sorted(by_shape.items())]
 
+    x3 = net.gemm_backend == "x3"
+    peak = PEAK_BF16_DENSE_TFLOPS / 6 if x3 else PEAK_FP32_MATRIX_TFLOPS
+    kernel_desc = ("gemm_x3_kernel (fp32 operands split into 3 bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per product, fp32 "
+                   "accumulate; peak = bf16 dense 2500 TFLOP/s / 6; achieved = fp32-equivalent algorithmic flops; all "
+                   "epilogue instantiations; the fused K^T V epilogue's own MFMAs are not counted)") if x3 else \
+                  ("gemm_f32_kernel (v_mfma_f32_32x32x2_f32; all epilogue instantiations; the fused K^T V epilogue's own "
+                   "MFMAs are not counted as algorithmic flops)")
     if rank == 0:
         total_pairs = B * world * args.steps
         out = {
@@ -233,10 +243,13 @@ def main():
                                    + ", batch-of-pairs=%d per GPU, A1-A10 per pair (forward 6+6 layers d_model 256, 1-NN thresh %g, "
                                      "Kabsch, RE/TE), random-init weights seed 0" % (B, dis_thresh),
                        "pairs_per_step_per_gpu": B, "mean_src_points": round(float(np.mean(batch.src_len)), 1),
-                       "mean_tgt_points": round(float(np.mean(batch.tgt_len)), 1), "parallelism": "dp%d (pairs sharded, metric-row all-gather)" % world},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32; all epilogue instantiations; the fused K^T V epilogue's own MFMAs are not counted as algorithmic flops)",
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                       "mean_tgt_points": round(float(np.mean(batch.tgt_len)), 1), "parallelism": "dp%d (pairs sharded, metric-row all-gather)" % world,
+                       "gemm_backend": net.gemm_backend},
+            "roofline": {"bound": "mfma", "kernel": kernel_desc,
+                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "mfma_tflops_issued": round(achieved * (6 if x3 else 1), 1),
+                         "frac_of_fp32_matrix_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
                          "launches": gemm_launches, "avg_ms": round(gemm_ms / gemm_launches, 4),
                          "algorithmic_gflop_per_step": round(algo_flops_step / 1e9, 1),
                          "row_padding_efficiency": round(pad_eff, 4), "by_kernel": by_kernel,

@@ -122,7 +122,11 @@ int scream_coor_head(const float* X, const float* W, const float* b, float* out,
 /* ---- Whole forward pass of PointTransformer over a packed batch (A1-A6).
  * Replaces models/pointnet.py:38-60 for B pairs at once (the reference asserts B == 1, :39-40). */
 typedef struct {
+    /* Weight matrices are fp32 [N,K] when scream_model_t.gemm_planes == 0 and bf16 planes [3][N][K] (see
+     * scream_gemm_x3_f32; the pointers are then really const void*) when it is 1. */
     const float* wqkv; /* [768,256]: q_proj | k_proj[0:128] | v_proj[0:128] | k_proj[128:256] | v_proj[128:256] */
+    const float* wq;   /* rows [0,256) of wqkv as their own matrix (cross layers project q and k/v from different clouds) */
+    const float* wkv;  /* rows [256,768) of wqkv as their own matrix */
     const float* wm;   /* merge [256,256] */
     const float* w1;   /* mlp.0 [1024,256] */
     const float* w2;   /* mlp.2 [256,1024] */
@@ -144,6 +148,10 @@ typedef struct {
      * (models/pointnet.py:113-118,143-145): HOST array of n_self layers applied to the SECOND clouds (stem_dem) while
      * layers_host[0..n_self) (stem_dsm) are applied to the first clouds only. */
     const scream_layer_t* stem_tgt_layers_host;
+    /* 0: fp32 weights, fp32-input MFMA GEMMs (scream_gemm_f32).  1: every weight MATRIX above (wqkv/wq/wkv/wm/w1/w2,
+     * c0_w, c2_w) is a [3][N][K] bf16 plane block and the GEMMs run on scream_gemm_x3_f32 -- same fp32 results to
+     * rounding (tests/test_gpu_parity.py holds both to the same tolerances). */
+    int32_t gemm_planes;
 } scream_model_t;
 
 typedef struct {

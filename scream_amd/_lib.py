@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscream_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -21,7 +21,7 @@ c_u64p = C.POINTER(C.c_uint64)
 
 
 class LayerT(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "wm", "w1", "w2", "g1", "b1", "g2", "b2")]
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "wq", "wkv", "wm", "w1", "w2", "g1", "b1", "g2", "b2")]
 
 
 class ModelT(C.Structure):
@@ -29,7 +29,7 @@ class ModelT(C.Structure):
                 ("emb_b", C.c_void_p), ("pre_g", C.c_void_p), ("pre_b", C.c_void_p),
                 ("layers_host", C.POINTER(LayerT)), ("c0_w", C.c_void_p), ("c0_b", C.c_void_p),
                 ("c2_w", C.c_void_p), ("c2_b", C.c_void_p), ("c4_w", C.c_void_p), ("c4_b", C.c_void_p),
-                ("stem_tgt_layers_host", C.POINTER(LayerT))]
+                ("stem_tgt_layers_host", C.POINTER(LayerT)), ("gemm_planes", C.c_int32)]
 
 
 class BatchT(C.Structure):

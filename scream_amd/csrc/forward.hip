@@ -79,12 +79,23 @@ enum { TR_EMBED = 100, TR_KV_REDUCE = 101, TR_ATTN_APPLY = 102, TR_COOR_HEAD = 1
 struct Ctx {
     void* st;
     Trace* tr;
+    bool planes;  // scream_model_t.gemm_planes: weights are bf16 plane blocks, GEMMs on the split kernel
 };
 
 int gemm(const Ctx& c, const float* A, int64_t lda, const float* W, float* C, int64_t ldc, int64_t M, int N, int K,
          int epi, int n_act, const float* bias, const float* res, const float* g, const float* b) {
     Scope sc(c.tr, epi, M, N, K, c.st);
+    if (c.planes) return scream_gemm_x3_f32(A, lda, W, C, ldc, M, N, K, epi, n_act, bias, res, D, g, b, c.st);
     return scream_gemm_f32(A, lda, W, C, ldc, M, N, K, epi, n_act, bias, res, D, g, b, c.st);
+}
+
+int gemm_qkv(const Ctx& c, const float* A, const float* W, float* Q, int64_t M, int N, int n_q, const scream_batch_t& b,
+             int64_t row_base, float* kvp) {
+    Scope sc(c.tr, 5, M, N, D, c.st);
+    if (c.planes)
+        return scream_gemm_qkv_x3_f32(A, D, W, Q, D, M, N, D, n_q, b.tile_cloud, b.cloud_row0, b.cloud_len, row_base, kvp,
+                                      c.st);
+    return scream_gemm_qkv_f32(A, D, W, Q, D, M, N, D, n_q, b.tile_cloud, b.cloud_row0, b.cloud_len, row_base, kvp, c.st);
 }
 
 // merge + norm1 + FFN + norm2 (models/transformer.py:83-88); x is the block input (residual of BOTH norms).
@@ -100,8 +111,6 @@ int mha_tail(const Ctx& c, const scream_layer_t& L, const Workspace& w, const fl
     return 0;
 }
 
-enum { TR_QKV = 5 };
-
 // Self attention over packed rows [row0, row0 + rows) whose clouds are [cloud_begin, cloud_begin + n_clouds)
 // (transformer.py:74-90 with q = k = v).  x / y are the full feature buffers (row 0 = packed row 0).
 // The q/k/v projection reduces K^T V in its epilogue, so K' and V never reach HBM.
@@ -110,11 +119,7 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
     const float* xr = x + row0 * D;
     float* qr = w.q + row0 * D;
     float* kvp = w.kvp + row0 / SCREAM_ROW_TILE * SCREAM_NHEAD * KV_ELEMS;
-    {
-        Scope sc(c.tr, TR_QKV, rows, 3 * D, D, c.st);
-        TRY(scream_gemm_qkv_f32(xr, D, L.wqkv, qr, D, rows, 3 * D, D, D, b.tile_cloud, b.cloud_row0, b.cloud_len, row0,
-                                kvp, c.st));
-    }
+    TRY(gemm_qkv(c, xr, L.wqkv, qr, rows, 3 * D, D, b, row0, kvp));
     {
         Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
         TRY(scream_kv_finalize(kvp, b.cloud_row0, b.cloud_len, row0, cloud_begin, n_clouds, w.kv, c.st));
@@ -131,12 +136,8 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
 int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x_src,
               const float* x_tgt, float* y) {
     const int64_t rs = b.rows_src, rt = b.rows_total - b.rows_src;
-    TRY(gemm(c, x_src, D, L.wqkv, w.q, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr));
-    {
-        Scope sc(c.tr, TR_QKV, rt, 2 * D, D, c.st);
-        TRY(scream_gemm_qkv_f32(x_tgt, D, L.wqkv + (int64_t)D * D, nullptr, 0, rt, 2 * D, D, 0, b.tile_cloud, b.cloud_row0,
-                                b.cloud_len, rs, w.kvp, c.st));
-    }
+    TRY(gemm(c, x_src, D, L.wq, w.q, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr));
+    TRY(gemm_qkv(c, x_tgt, L.wkv, nullptr, rt, 2 * D, 0, b, rs, w.kvp));
     {
         Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
         TRY(scream_kv_finalize(w.kvp, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs, w.kv, c.st));
@@ -150,8 +151,8 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
 
 }  // namespace
 
-extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi4"; }
-extern "C" int scream_abi_version(void) { return 4; }
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi5"; }
+extern "C" int scream_abi_version(void) { return 5; }
 
 extern "C" void* scream_trace_create(int32_t capacity) {
     if (capacity <= 0) return nullptr;
@@ -210,14 +211,14 @@ extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t*
     SCREAM_REQUIRE(model && batch && workspace && src_pred, SCREAM_EINVAL);
     const scream_model_t& m = *model;
     const scream_batch_t& b = *batch;
-    SCREAM_REQUIRE(m.layers_host && m.n_self >= 0 && m.n_cross >= 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE(m.layers_host && m.n_self >= 0 && m.n_cross >= 0 && (m.gemm_planes == 0 || m.gemm_planes == 1), SCREAM_EINVAL);
     SCREAM_REQUIRE(b.n_pairs > 0 && b.rows_src > 0 && b.rows_total > b.rows_src && b.max_chunks > 0, SCREAM_EINVAL);
     SCREAM_REQUIRE(b.rows_src % SCREAM_ROW_TILE == 0 && b.rows_total % SCREAM_ROW_TILE == 0, SCREAM_EUNSUPPORTED);
     SCREAM_REQUIRE(b.xyz && b.center && b.tile_cloud && b.cloud_row0 && b.cloud_len, SCREAM_EINVAL);
     uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
     const Workspace w = carve(reinterpret_cast<void*>(base), b.rows_total, b.n_pairs, b.max_chunks);
     SCREAM_REQUIRE((int64_t)(base - reinterpret_cast<uintptr_t>(workspace)) + w.bytes <= workspace_bytes, SCREAM_EINVAL);
-    const Ctx c{stream, reinterpret_cast<Trace*>(trace)};
+    const Ctx c{stream, reinterpret_cast<Trace*>(trace), m.gemm_planes != 0};
 
     const int64_t rs = b.rows_src, ra = b.rows_total;
     {

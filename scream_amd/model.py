@@ -9,6 +9,7 @@ MI355X raises: there is no CPU path in the product.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -88,8 +89,12 @@ class PointTransformer(nn.Module):
     def _stem_tgt_modules(self) -> Optional[List[_MHAParams]]:
         return None  # PointTransformer: one stem for both clouds
 
+    # GEMM path of the forward: "x3" = bf16 matrix cores with 3-way operand splitting (fp32-level accuracy, ~1.5x
+    # the throughput), "f32" = fp32-input MFMA.  Both are held to the same parity tolerances; SCREAM_GEMM overrides.
+    gemm_backend = os.environ.get("SCREAM_GEMM", "x3")
+
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.gemm_backend,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _pack_weights(self):
         sig = self._signature()
@@ -106,6 +111,17 @@ class PointTransformer(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
+        if self.gemm_backend not in ("x3", "f32"):
+            raise ValueError("gemm_backend must be 'x3' or 'f32', got %r" % (self.gemm_backend,))
+        planes = self.gemm_backend == "x3"
+
+        def dev_mat(t):  # a weight MATRIX: fp32 [N,K], or its three bf16 planes for the split GEMM
+            if not planes:
+                return dev_f32(t)
+            t = ops.split_planes(t.detach().to(device=dev, dtype=torch.float32))
+            keep.append(t)
+            return t.data_ptr()
+
         mods = self._layer_modules()
         tgt_mods = self._stem_tgt_modules() or []
         layers = (_lib.LayerT * len(mods))()
@@ -114,10 +130,13 @@ class PointTransformer(nn.Module):
             # [q | k heads 0-3 | v heads 0-3 | k heads 4-7 | v heads 4-7]: a 256-wide GEMM tile then holds K and V of
             # four heads for the same tokens, which is what the fused K^T V epilogue needs (include/scream_hip.h)
             k, v = m.k_proj.weight, m.v_proj.weight
-            L.wqkv = dev_f32(torch.cat([m.q_proj.weight, k[:128], v[:128], k[128:], v[128:]], dim=0))
-            L.wm = dev_f32(m.merge.weight)
-            L.w1 = dev_f32(m.mlp[0].weight)
-            L.w2 = dev_f32(m.mlp[2].weight)
+            wkv = torch.cat([k[:128], v[:128], k[128:], v[128:]], dim=0)
+            L.wqkv = dev_mat(torch.cat([m.q_proj.weight, wkv], dim=0))
+            L.wq = dev_mat(m.q_proj.weight)
+            L.wkv = dev_mat(wkv)
+            L.wm = dev_mat(m.merge.weight)
+            L.w1 = dev_mat(m.mlp[0].weight)
+            L.w2 = dev_mat(m.mlp[2].weight)
             L.g1, L.b1 = dev_f32(m.norm1.weight), dev_f32(m.norm1.bias)
             L.g2, L.b2 = dev_f32(m.norm2.weight), dev_f32(m.norm2.bias)
         mt = _lib.ModelT()
@@ -128,8 +147,9 @@ class PointTransformer(nn.Module):
         mt.pre_g, mt.pre_b = dev_f32(self.pre_norm.weight), dev_f32(self.pre_norm.bias)
         mt.layers_host = C.cast(layers, C.POINTER(_lib.LayerT))
         mt.stem_tgt_layers_host = C.cast(tgt_layers, C.POINTER(_lib.LayerT)) if tgt_mods else None
-        mt.c0_w, mt.c0_b = dev_f32(self.coor_mlp[0].weight[:, :, 0]), dev_f32(self.coor_mlp[0].bias)
-        mt.c2_w, mt.c2_b = dev_f32(self.coor_mlp[2].weight[:, :, 0]), dev_f32(self.coor_mlp[2].bias)
+        mt.gemm_planes = int(planes)
+        mt.c0_w, mt.c0_b = dev_mat(self.coor_mlp[0].weight[:, :, 0]), dev_f32(self.coor_mlp[0].bias)
+        mt.c2_w, mt.c2_b = dev_mat(self.coor_mlp[2].weight[:, :, 0]), dev_f32(self.coor_mlp[2].bias)
         mt.c4_w, mt.c4_b = dev_f32(self.coor_mlp[4].weight[:, :, 0]), dev_f32(self.coor_mlp[4].bias)
         self._packed = (mt, (layers, tgt_layers), keep)
         self._packed_sig = sig
