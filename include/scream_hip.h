@@ -77,13 +77,17 @@ int scream_kv_finalize(const float* kv_partial, const int32_t* cloud_row0, const
 
 /* ---- The same two GEMM entry points on the bf16 matrix cores with 3-way operand splitting (fp32-level accuracy:
  * x = x0 + x1 + x2 in bf16, six bf16 MFMAs per 16-deep step, fp32 accumulate; scream_amd/csrc/gemm_x3.hip).
- * W_planes is the weight matrix pre-split on the host: [3][N][K] bf16 (plane p of W: p0 = bf16(W),
- * p1 = bf16(W - p0), p2 = bf16(W - p0 - p1)); A, C, residual, bias stay fp32.  M % 128 == 0. */
-int scream_gemm_x3_f32(const float* A, int64_t lda, const void* W_planes, float* C, int64_t ldc, int64_t M,
+ * The weight matrix is pre-split and re-tiled ONCE by scream_pack_w_x3 (device to device): W [N,K] fp32 ->
+ * W_packed, 6*N*K bytes: [3 planes][K/32 k-tiles][N][32] bf16 with plane p0 = bf16(W), p1 = bf16(W - p0),
+ * p2 = bf16(W - p0 - p1), stored k-tile by k-tile in the order the kernel stages it in LDS.  A, C, residual and
+ * bias stay fp32.  M % 128 == 0, N % 256 == 0, K % 64 == 0.  A row-block [n0, n0 + n) of W must be packed on its
+ * own to be used as a GEMM operand on its own. */
+int scream_pack_w_x3(const float* W, int32_t N, int32_t K, void* W_packed, void* stream);
+int scream_gemm_x3_f32(const float* A, int64_t lda, const void* W_packed, float* C, int64_t ldc, int64_t M,
                        int32_t N, int32_t K, int32_t epilogue, int32_t n_act, const float* bias,
                        const float* residual, int64_t ldr, const float* gamma, const float* beta,
                        void* stream);
-int scream_gemm_qkv_x3_f32(const float* A, int64_t lda, const void* W_planes, float* Q, int64_t ldq,
+int scream_gemm_qkv_x3_f32(const float* A, int64_t lda, const void* W_packed, float* Q, int64_t ldq,
                            int64_t M, int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
                            const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
                            float* kv_partial, void* stream);
@@ -122,8 +126,8 @@ int scream_coor_head(const float* X, const float* W, const float* b, float* out,
 /* ---- Whole forward pass of PointTransformer over a packed batch (A1-A6).
  * Replaces models/pointnet.py:38-60 for B pairs at once (the reference asserts B == 1, :39-40). */
 typedef struct {
-    /* Weight matrices are fp32 [N,K] when scream_model_t.gemm_planes == 0 and bf16 planes [3][N][K] (see
-     * scream_gemm_x3_f32; the pointers are then really const void*) when it is 1. */
+    /* Weight matrices are fp32 [N,K] when scream_model_t.gemm_planes == 0 and scream_pack_w_x3 images of them
+     * (the pointers are then really const void*) when it is 1. */
     const float* wqkv; /* [768,256]: q_proj | k_proj[0:128] | v_proj[0:128] | k_proj[128:256] | v_proj[128:256] */
     const float* wq;   /* rows [0,256) of wqkv as their own matrix (cross layers project q and k/v from different clouds) */
     const float* wkv;  /* rows [256,768) of wqkv as their own matrix */
@@ -149,7 +153,7 @@ typedef struct {
      * layers_host[0..n_self) (stem_dsm) are applied to the first clouds only. */
     const scream_layer_t* stem_tgt_layers_host;
     /* 0: fp32 weights, fp32-input MFMA GEMMs (scream_gemm_f32).  1: every weight MATRIX above (wqkv/wq/wkv/wm/w1/w2,
-     * c0_w, c2_w) is a [3][N][K] bf16 plane block and the GEMMs run on scream_gemm_x3_f32 -- same fp32 results to
+     * c0_w, c2_w) is a scream_pack_w_x3 image and the GEMMs run on scream_gemm_x3_f32 -- same fp32 results to
      * rounding (tests/test_gpu_parity.py holds both to the same tolerances). */
     int32_t gemm_planes;
 } scream_model_t;

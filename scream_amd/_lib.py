@@ -46,6 +46,7 @@ SIGNATURES = {
     "scream_gemm_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, I32, V, V, I64, V, V, V]),
     "scream_gemm_qkv_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, V, V, V, I64, V, V]),
     "scream_kv_finalize": (C.c_int, [V, V, V, I64, I32, I32, V, V]),
+    "scream_pack_w_x3": (C.c_int, [V, I32, I32, V, V]),
     "scream_gemm_x3_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, I32, V, V, I64, V, V, V]),
     "scream_gemm_qkv_x3_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, V, V, V, I64, V, V]),
     "scream_pe_embed_ln": (C.c_int, [V, V, V, V, V, V, V, V, V, I64, V]),

@@ -16,6 +16,12 @@
 // 64 contiguous bytes of row r per k-tile straight into registers and splits them there (v_cvt_pk_bf16_f32 + 2 subs per
 // plane).  Lane-half h owns k = 16h + 8s + j of step s for both operands.  A dedicated 64 KiB LDS region holds the
 // epilogue slabs, so the first k-tile of the next output tile is already in flight during the epilogue.
+// Tuning aid (tools/x3_ablate.py builds variants): bit 0 no epilogue, 1 no W DMA after the first k-tile, 2 no A loads
+// after the first, 3 no MFMAs, 4 no LDS fragment reads, 5 no operand split.  Always 0 in libscream_hip.so.
+#ifndef X3_ABLATE
+#define X3_ABLATE 0
+#endif
+#include "gemm_epilogue.h"
 #include "gemm_epilogue.h"
 
 namespace {
@@ -59,15 +65,16 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
         const unsigned xcd = v & 7u;
         return (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (v >> 3);
     };
-    // DMA: 48 one-KiB pieces per k-tile (3 planes x 16 pieces of 16 rows x 64 B), six per wave.  Piece id -> (plane,
-    // q) is wave-uniform; the per-lane part (row q*16 + lane/4, source chunk (lane&3) ^ ((row>>2)&3) = (lane&3) ^
-    // ((lane>>4)&3)) does not depend on the piece, so one per-lane base pointer serves all six.
-    const __bf16* w_lane = Wp + (int64_t)(lane >> 2) * K + (((lane & 3) ^ ((lane >> 4) & 3)) << 3);
+    // DMA: 48 one-KiB pieces per k-tile (3 planes x 16 pieces of 16 rows x 64 B), six per wave.  The packed weight
+    // image (scream_pack_w_x3) is stored k-tile by k-tile exactly as it sits in LDS, chunk swizzle included, so
+    // every piece is 1 KiB of CONTIGUOUS memory (eight full 128-byte lines, no over-fetch) and the per-lane part
+    // of the address is just lane * 16 bytes.
+    const __bf16* w_lane = Wp + lane * 8;
     auto dma_w = [&](int n0, int stage, int kt) {
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             const int id = wave * 6 + u, plane = id >> 4, q = id & 15;
-            const int64_t soff = ((int64_t)plane * N + n0 + q * 16) * K + kt * XBK;  // scalar
+            const int64_t soff = (((int64_t)plane * (K / XBK) + kt) * N + n0 + q * 16) * XBK;  // scalar
             __builtin_amdgcn_global_load_lds((gptr_t)(w_lane + soff),
                                              (lptr_t)(smem + stage * STAGE_BYTES + plane * PLANE_BYTES + q * 1024), 16, 0, 0);
         }
@@ -104,9 +111,11 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(ac[j]));
             if (kt + 1 < KT) {
-                dma_w(n0, stage ^ 1, kt + 1);
+                if (!(X3_ABLATE & 2)) dma_w(n0, stage ^ 1, kt + 1);
+                if (!(X3_ABLATE & 4)) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) an[j] = ld4(ga + (kt + 1) * XBK + j * 4);
+                    for (int j = 0; j < 4; ++j) an[j] = ld4(ga + (kt + 1) * XBK + j * 4);
+                }
             }
             const char* wb = smem + stage * STAGE_BYTES;
             bf16x8 fb[2][3];
@@ -115,15 +124,26 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 pa0, pa1, pa2;
-                split3(ac[2 * s], ac[2 * s + 1], pa0, pa1, pa2);
+                if (X3_ABLATE & 32) {
+                    pa0 = __builtin_bit_cast(bf16x8, ac[2 * s]);
+                    pa1 = __builtin_bit_cast(bf16x8, ac[2 * s + 1]);
+                    pa2 = pa0;
+                } else {
+                    split3(ac[2 * s], ac[2 * s + 1], pa0, pa1, pa2);
+                }
 #pragma unroll
                 for (int tn = 0; tn < 8; ++tn) {
                     const int cur = tn & 1, nxt = cur ^ 1;
-                    if (s * 8 + tn + 1 < 16) {  // fragments of the next (step, N-tile) are requested one group ahead
+                    if (s * 8 + tn + 1 < 16 && !(X3_ABLATE & 16)) {  // fragments of the next (step, N-tile) are requested one group ahead
                         const int s2 = (s * 8 + tn + 1) >> 3, t2 = (s * 8 + tn + 1) & 7;
 #pragma unroll
                         for (int p = 0; p < 3; ++p)
                             fb[nxt][p] = *reinterpret_cast<const bf16x8*>(wb + p * PLANE_BYTES + t2 * 32 * 64 + boff[s2]);
+                    }
+                    if (X3_ABLATE & 8) {
+                        acc[tn][0] += (float)pa0[0] + (float)pa1[1] + (float)pa2[2] + (float)fb[cur][0][0] +
+                                      (float)fb[cur][1][0] + (float)fb[cur][2][0];
+                        continue;
                     }
                     acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa2, fb[cur][0], acc[tn], 0, 0, 0);
                     acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, fb[cur][1], acc[tn], 0, 0, 0);
@@ -164,7 +184,16 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
 #pragma unroll
             for (int j = 0; j < 4; ++j) a0[j] = ld4(ga + j * 4);
         }
-        gemm_epilogue<EPI, XWAVES>(acc, slabs, wave, lane, tid, rows_cur, m0_cur, n0_cur, ep, C, ldc);
+        if (X3_ABLATE & 1) {
+            float keep = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < 8; ++tn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) keep += acc[tn][e];
+            if (keep == 123.456f) C[0] = keep;
+        } else {
+            gemm_epilogue<EPI, XWAVES>(acc, slabs, wave, lane, tid, rows_cur, m0_cur, n0_cur, ep, C, ldc);
+        }
         if (!has_next) break;
         v = v_next;
         if (EPI == SCREAM_EPI_RES_LN) {
@@ -174,6 +203,24 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
         }
         __syncthreads();
     }
+}
+
+// W [N][K] fp32 -> packed planes [3][K/32][N][32] bf16; 16-byte chunk c of a row's 32-deep k-slice is stored at
+// chunk c ^ ((n >> 2) & 3).  One thread per (n, k-tile, stored chunk).
+__global__ void pack_w_x3_kernel(const float* __restrict__ W, int N, int K, __bf16* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int KT = K / XBK;
+    if (t >= (int64_t)N * KT * 4) return;
+    const int cs = (int)(t & 3), n = (int)((t >> 2) % N), kt = (int)((t >> 2) / N);
+    const int c = cs ^ ((n >> 2) & 3);
+    const float* src = W + (int64_t)n * K + kt * XBK + c * 8;
+    bf16x8 p0, p1, p2;
+    split3(ld4(src), ld4(src + 4), p0, p1, p2);
+    const int64_t plane = (int64_t)KT * N * XBK;
+    __bf16* dst = out + ((int64_t)kt * N + n) * XBK + cs * 8;
+    *reinterpret_cast<bf16x8*>(dst) = p0;
+    *reinterpret_cast<bf16x8*>(dst + plane) = p1;
+    *reinterpret_cast<bf16x8*>(dst + 2 * plane) = p2;
 }
 
 template <int EPI>
@@ -191,6 +238,17 @@ int launch_x3(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc
 }
 
 }  // namespace
+
+extern "C" int scream_pack_w_x3(const float* W, int32_t N, int32_t K, void* packed, void* stream) {
+    SCREAM_REQUIRE(W && packed, SCREAM_EINVAL);
+    SCREAM_REQUIRE(N > 0 && N % 4 == 0 && K > 0 && K % XBK == 0, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(W) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed) & 15) == 0, SCREAM_EINVAL);
+    const int64_t threads = (int64_t)N * (K / XBK) * 4;
+    pack_w_x3_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(
+        W, N, K, reinterpret_cast<__bf16*>(packed));
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int scream_gemm_x3_f32(const float* A, int64_t lda, const void* W_planes, float* C, int64_t ldc, int64_t M,
                                   int32_t N, int32_t K, int32_t epilogue, int32_t n_act, const float* bias,

@@ -53,13 +53,13 @@ def gemm_f32(A: torch.Tensor, W: torch.Tensor, epilogue: int = EPI_NONE, n_act: 
 
 
 def split_planes(W: torch.Tensor) -> torch.Tensor:
-    """[N,K] fp32 -> [3,N,K] bf16 planes with p0 + p1 + p2 == W exactly (weight repacking for the x3 GEMMs)."""
-    W = W.detach().float()
-    p0 = W.to(torch.bfloat16)
-    r1 = W - p0.float()
-    p1 = r1.to(torch.bfloat16)
-    p2 = (r1 - p1.float()).to(torch.bfloat16)
-    return torch.stack([p0, p1, p2]).contiguous()
+    """[N,K] fp32 (on the GPU) -> the packed operand of the x3 GEMMs, [3, K/32, N, 32] bf16 (scream_pack_w_x3):
+    planes p0 + p1 + p2 == W exactly, re-tiled k-tile by k-tile in the kernel's LDS order."""
+    W = W.detach().to(torch.float32).contiguous()
+    N, K = W.shape
+    out = torch.empty(3, K // 32, N, 32, device=W.device, dtype=torch.bfloat16)
+    check(_lib.load().scream_pack_w_x3(_p(W), N, K, _p(out, torch.bfloat16), _stream()), "scream_pack_w_x3")
+    return out
 
 
 def gemm_x3(A: torch.Tensor, Wp: torch.Tensor, epilogue: int = EPI_NONE, n_act: int = 0,
@@ -68,8 +68,8 @@ def gemm_x3(A: torch.Tensor, Wp: torch.Tensor, epilogue: int = EPI_NONE, n_act: 
             out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """gemm_f32's contract on the bf16 matrix cores (3-way split, fp32-level accuracy); Wp = split_planes(W)."""
     M, K = A.shape
-    N = Wp.shape[1]
-    assert Wp.shape == (3, N, K) and Wp.dtype == torch.bfloat16
+    N = Wp.shape[2]
+    assert Wp.shape == (3, K // 32, N, 32) and Wp.dtype == torch.bfloat16
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
     check(_lib.load().scream_gemm_x3_f32(_p(A), A.stride(0), _p(Wp, torch.bfloat16), _p(out), out.stride(0), M, N, K,
@@ -83,9 +83,9 @@ def gemm_qkv(A: torch.Tensor, W: torch.Tensor, n_q: int, tile_cloud, cloud_row0,
     """Fused q/k/v projection (scream_gemm_qkv_f32).  Returns (Q' [M,256] or None, kv_partial [M/128,8,1056])."""
     M, K = A.shape
     N = W.shape[0]
-    x3 = W.dim() == 3  # [3,N,K] bf16 planes -> the split kernel
+    x3 = W.dim() == 4  # packed bf16 planes (split_planes) -> the split kernel
     if x3:
-        N = W.shape[1]
+        N = W.shape[2]
     Q = torch.empty(M, n_q, device=A.device, dtype=torch.float32) if n_q else None
     part = torch.empty(M // ROW_TILE, 8, KV_ELEMS, device=A.device, dtype=torch.float32)
     fn = _lib.load().scream_gemm_qkv_x3_f32 if x3 else _lib.load().scream_gemm_qkv_f32
