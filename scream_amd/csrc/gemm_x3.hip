@@ -21,6 +21,8 @@
 #ifndef X3_ABLATE
 #define X3_ABLATE 0
 #endif
+#include <type_traits>
+
 #include "gemm_epilogue.h"
 #include "gemm_epilogue.h"
 
@@ -47,6 +49,14 @@ __device__ __forceinline__ void split3(const f32x4 lo, const f32x4 hi, bf16x8& p
         p1[i] = b;
         p2[i] = (__bf16)(r1 - (float)b);
     }
+}
+
+// s_waitcnt vmcnt(N) lgkmcnt(0) + workgroup barrier: the N youngest vector-memory operations of this wave (the A
+// loads of the k-tile after next) stay in flight across the barrier.
+template <int N>
+__device__ __forceinline__ void ring_barrier() {
+    __builtin_amdgcn_s_waitcnt(0x0070 | (N & 15) | ((N >> 4) << 14));
+    __builtin_amdgcn_s_barrier();
 }
 
 template <int EPI>
@@ -93,11 +103,16 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
     bool rows_ok = m0 + wave * 32 < M;
     const float* ga = a_ptr(m0, rows_ok);
 
-    f32x4 a0[4], a1[4];
-    dma_w(n0, 0, 0);
+    // A registers: three sets, requested TWO k-tiles ahead (activations that only one output tile reads come from
+    // HBM: one k-tile of lead did not cover that latency, profiles/r01_x3_ablation.txt)
+    f32x4 a0[4], a1[4], a2[4];
+    auto load_a = [&](f32x4 (&a)[4], int kt) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a0[j] = ld4(ga + j * 4);
-    __syncthreads();
+        for (int j = 0; j < 4; ++j) a[j] = ld4(ga + kt * XBK + j * 4);
+    };
+    dma_w(n0, 0, 0);
+    load_a(a0, 0);
+    load_a(a1, 1);
 
     for (;;) {
         f32x16 acc[8];
@@ -106,17 +121,20 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[tn][e] = 0.f;
 
-        auto step = [&](int kt, int stage, f32x4 (&ac)[4], f32x4 (&an)[4]) {
-            // retire this k-tile's A loads before anything younger is issued (see gemm_f32.hip)
+        // One k-tile.  Issue order D(kt+1) then A(kt+2), so the wait at the end of the step -- everything but the
+        // four youngest operations -- covers D(kt+1) (and A(kt+1), older still) and leaves A(kt+2) in flight.
+        // tail: 0 steady, 1 = only D(kt+1) left to request, 2 = nothing.  Compile-time on purpose: with a conditional
+        // load inside the loop hipcc stops counting and puts s_waitcnt vmcnt(0) in front of the first use of ac.
+        auto step = [&](auto tail, int kt, int stage, f32x4 (&ac)[4], f32x4 (&an2)[4]) {
+            constexpr int TAIL = decltype(tail)::value;
+            // everything but the four youngest operations (A(kt+1), requested one step ago) has landed: W k-tile kt in
+            // LDS for every wave, A(kt) in registers; all reads of the other stage are done
+            if (TAIL <= 1) ring_barrier<4>(); else ring_barrier<0>();
+            // pin the compiler's own wait for this k-tile's A registers here, before anything younger is issued
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(ac[j]));
-            if (kt + 1 < KT) {
-                if (!(X3_ABLATE & 2)) dma_w(n0, stage ^ 1, kt + 1);
-                if (!(X3_ABLATE & 4)) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) an[j] = ld4(ga + (kt + 1) * XBK + j * 4);
-                }
-            }
+            if (TAIL <= 1 && !(X3_ABLATE & 2)) dma_w(n0, stage ^ 1, kt + 1);
+            if (TAIL == 0 && !(X3_ABLATE & 4)) load_a(an2, kt + 2);
             const char* wb = smem + stage * STAGE_BYTES;
             bf16x8 fb[2][3];
 #pragma unroll
@@ -153,18 +171,37 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
                     acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, fb[cur][0], acc[tn], 0, 0, 0);
                     // first MFMA, then the three prefetch reads, then the other five MFMAs (hipcc emits lgkmcnt(0)
                     // rather than a counted wait while an LDS-DMA is in flight)
+#if !defined(X3_SCHED) || X3_SCHED == 0
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+#elif X3_SCHED == 1
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#elif X3_SCHED == 2
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            __syncthreads();  // all reads of `stage` done; k-tile kt+1 landed (vmcnt(0) drained by the barrier's fence)
         };
-        for (int kt = 0; kt < KT; kt += 2) {
-            step(kt, 0, a0, a1);
-            step(kt + 1, 1, a1, a0);
+        constexpr std::integral_constant<int, 0> steady{};
+        constexpr std::integral_constant<int, 1> tail1{};
+        constexpr std::integral_constant<int, 2> tail2{};
+        for (int kt = 0; kt < KT - 2; kt += 3) {  // (KT - 2) % 3 == 0 (host check); KT is even, so stage = kt & 1
+            step(steady, kt, kt & 1, a0, a2);
+            step(steady, kt + 1, (kt + 1) & 1, a1, a0);
+            step(steady, kt + 2, kt & 1, a2, a1);
         }
+        step(tail1, KT - 2, 0, a0, a2);
+        step(tail2, KT - 1, 1, a1, a2);
 
         // next output tile: its first k-tile lands under the epilogue (the slabs have their own LDS region)
         const unsigned v_next = v + gridDim.x;
@@ -181,8 +218,8 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
         }
         if (EPI != SCREAM_EPI_RES_LN && has_next) {
             dma_w(n0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a0[j] = ld4(ga + j * 4);
+            load_a(a0, 0);
+            load_a(a1, 1);
         }
         if (X3_ABLATE & 1) {
             float keep = 0.f;
@@ -198,10 +235,9 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
         v = v_next;
         if (EPI == SCREAM_EPI_RES_LN) {
             dma_w(n0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a0[j] = ld4(ga + j * 4);
+            load_a(a0, 0);
+            load_a(a1, 1);
         }
-        __syncthreads();
     }
 }
 
@@ -255,7 +291,7 @@ extern "C" int scream_gemm_x3_f32(const float* A, int64_t lda, const void* W_pla
                                   const float* residual, int64_t ldr, const float* gamma, const float* beta,
                                   void* stream) {
     SCREAM_REQUIRE(A && W_planes && C, SCREAM_EINVAL);
-    SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K > 0 && K % 64 == 0, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K >= 64 && K % 32 == 0 && (K / 32 - 2) % 3 == 0, SCREAM_EUNSUPPORTED);  // K = 64 + 96 j
     SCREAM_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0 && ldc % 4 == 0, SCREAM_EINVAL);
     SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W_planes) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(C) & 15) == 0, SCREAM_EINVAL);
@@ -287,7 +323,7 @@ extern "C" int scream_gemm_qkv_x3_f32(const float* A, int64_t lda, const void* W
                                       const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
                                       float* kv_partial, void* stream) {
     SCREAM_REQUIRE(A && W_planes && kv_partial && tile_cloud && cloud_row0 && cloud_len, SCREAM_EINVAL);
-    SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K > 0 && K % 64 == 0, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K >= 64 && K % 32 == 0 && (K / 32 - 2) % 3 == 0, SCREAM_EUNSUPPORTED);  // K = 64 + 96 j
     SCREAM_REQUIRE((n_q == 0 || n_q == XBN) && N == n_q + 2 * XBN && row_base >= 0 && row_base % SCREAM_ROW_TILE == 0,
                    SCREAM_EUNSUPPORTED);
     SCREAM_REQUIRE(n_q == 0 || (Q && ldq >= n_q && ldq % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0), SCREAM_EINVAL);
