@@ -110,10 +110,19 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 4; ++j) a[j] = ld4(ga + kt * XBK + j * 4);
     };
-    dma_w(n0, 0, 0);
-    load_a(a0, 0);
-    load_a(a1, 1);
+    // issue order D(0), A(0), A(1): the first barrier's vmcnt(4) must leave exactly A(1) in flight
+    auto request_first = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        dma_w(n0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(a0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(a1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    request_first();
 
+    bf16x8 pa_s0[3];  // split planes of the first 16-deep step of the k-tile about to be computed
     for (;;) {
         f32x16 acc[8];
 #pragma unroll
@@ -121,87 +130,90 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[tn][e] = 0.f;
 
-        // One k-tile.  Issue order D(kt+1) then A(kt+2), so the wait at the end of the step -- everything but the
-        // four youngest operations -- covers D(kt+1) (and A(kt+1), older still) and leaves A(kt+2) in flight.
+        // One k-tile = two 16-deep MFMA steps over the eight N-tiles.  The barrier at the top is followed directly by
+        // MFMAs: the operand split of step 0 was done at the end of the previous k-tile (pa_s0), and the requests for
+        // the next k-tile -- D(kt+1), then A(kt+2), in that order so that vmcnt(4) at the next barrier leaves the A
+        // loads in flight -- are issued between the two steps instead of in the post-barrier bubble.
         // tail: 0 steady, 1 = only D(kt+1) left to request, 2 = nothing.  Compile-time on purpose: with a conditional
-        // load inside the loop hipcc stops counting and puts s_waitcnt vmcnt(0) in front of the first use of ac.
-        auto step = [&](auto tail, int kt, int stage, f32x4 (&ac)[4], f32x4 (&an2)[4]) {
-            constexpr int TAIL = decltype(tail)::value;
-            // everything but the four youngest operations (A(kt+1), requested one step ago) has landed: W k-tile kt in
-            // LDS for every wave, A(kt) in registers; all reads of the other stage are done
-            if (TAIL <= 1) ring_barrier<4>(); else ring_barrier<0>();
-            // pin the compiler's own wait for this k-tile's A registers here, before anything younger is issued
+        // load inside the loop hipcc stops counting and falls back to s_waitcnt vmcnt(0).
+        auto groups = [&](const char* wb, int s, const bf16x8 (&pa)[3], bf16x8 (&fb)[2][3]) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(ac[j]));
-            if (TAIL <= 1 && !(X3_ABLATE & 2)) dma_w(n0, stage ^ 1, kt + 1);
-            if (TAIL == 0 && !(X3_ABLATE & 4)) load_a(an2, kt + 2);
+            for (int tn = 0; tn < 8; ++tn) {
+                const int cur = tn & 1, nxt = cur ^ 1;
+                if (s * 8 + tn + 1 < 16 && !(X3_ABLATE & 16)) {  // fragments of the next (step, N-tile), one group ahead
+                    const int s2 = (s * 8 + tn + 1) >> 3, t2 = (s * 8 + tn + 1) & 7;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        fb[nxt][p] = *reinterpret_cast<const bf16x8*>(wb + p * PLANE_BYTES + t2 * 32 * 64 + boff[s2]);
+                }
+                if (X3_ABLATE & 8) {
+                    acc[tn][0] += (float)pa[0][0] + (float)pa[1][1] + (float)pa[2][2] + (float)fb[cur][0][0] +
+                                  (float)fb[cur][1][0] + (float)fb[cur][2][0];
+                    continue;
+                }
+                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[2], fb[cur][0], acc[tn], 0, 0, 0);
+                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], fb[cur][1], acc[tn], 0, 0, 0);
+                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], fb[cur][2], acc[tn], 0, 0, 0);
+                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], fb[cur][0], acc[tn], 0, 0, 0);
+                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], fb[cur][1], acc[tn], 0, 0, 0);
+                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], fb[cur][0], acc[tn], 0, 0, 0);
+                // first MFMA, then the three prefetch reads, then the other five MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto split_of = [&](const f32x4& lo, const f32x4& hi, bf16x8 (&pa)[3]) {
+            if (X3_ABLATE & 32) {
+                pa[0] = __builtin_bit_cast(bf16x8, lo);
+                pa[1] = __builtin_bit_cast(bf16x8, hi);
+                pa[2] = pa[0];
+            } else {
+                split3(lo, hi, pa[0], pa[1], pa[2]);
+            }
+        };
+        auto step = [&](auto tail, int kt, int stage, f32x4 (&ac)[4], f32x4 (&an1)[4], f32x4 (&an2)[4]) {
+            constexpr int TAIL = decltype(tail)::value;
+            // everything but the four youngest operations (A(kt+1)) has landed: W k-tile kt is in LDS for every wave,
+            // and every wave is done reading the other stage
+            if (TAIL <= 1) ring_barrier<4>(); else ring_barrier<0>();
             const char* wb = smem + stage * STAGE_BYTES;
             bf16x8 fb[2][3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) fb[0][p] = *reinterpret_cast<const bf16x8*>(wb + p * PLANE_BYTES + boff[0]);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 pa0, pa1, pa2;
-                if (X3_ABLATE & 32) {
-                    pa0 = __builtin_bit_cast(bf16x8, ac[2 * s]);
-                    pa1 = __builtin_bit_cast(bf16x8, ac[2 * s + 1]);
-                    pa2 = pa0;
-                } else {
-                    split3(ac[2 * s], ac[2 * s + 1], pa0, pa1, pa2);
-                }
-#pragma unroll
-                for (int tn = 0; tn < 8; ++tn) {
-                    const int cur = tn & 1, nxt = cur ^ 1;
-                    if (s * 8 + tn + 1 < 16 && !(X3_ABLATE & 16)) {  // fragments of the next (step, N-tile) are requested one group ahead
-                        const int s2 = (s * 8 + tn + 1) >> 3, t2 = (s * 8 + tn + 1) & 7;
-#pragma unroll
-                        for (int p = 0; p < 3; ++p)
-                            fb[nxt][p] = *reinterpret_cast<const bf16x8*>(wb + p * PLANE_BYTES + t2 * 32 * 64 + boff[s2]);
-                    }
-                    if (X3_ABLATE & 8) {
-                        acc[tn][0] += (float)pa0[0] + (float)pa1[1] + (float)pa2[2] + (float)fb[cur][0][0] +
-                                      (float)fb[cur][1][0] + (float)fb[cur][2][0];
-                        continue;
-                    }
-                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa2, fb[cur][0], acc[tn], 0, 0, 0);
-                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, fb[cur][1], acc[tn], 0, 0, 0);
-                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, fb[cur][2], acc[tn], 0, 0, 0);
-                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, fb[cur][0], acc[tn], 0, 0, 0);
-                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, fb[cur][1], acc[tn], 0, 0, 0);
-                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, fb[cur][0], acc[tn], 0, 0, 0);
-                    // first MFMA, then the three prefetch reads, then the other five MFMAs (hipcc emits lgkmcnt(0)
-                    // rather than a counted wait while an LDS-DMA is in flight)
-#if !defined(X3_SCHED) || X3_SCHED == 0
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
-#elif X3_SCHED == 1
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-#elif X3_SCHED == 2
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            groups(wb, 0, pa_s0, fb);
+            if (TAIL <= 1 && !(X3_ABLATE & 2)) dma_w(n0, stage ^ 1, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);  // the counted waits rely on this issue order: D(kt+1), then A(kt+2)
+            if (TAIL == 0 && !(X3_ABLATE & 4)) load_a(an2, kt + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 pa_s1[3];
+            split_of(ac[2], ac[3], pa_s1);
+            __builtin_amdgcn_sched_barrier(0);
+            groups(wb, 1, pa_s1, fb);
+            if (TAIL <= 1) {  // A(kt+1) is older than what was requested above: wait for it alone, split its first half
+                if (TAIL == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 10); else __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
+                asm volatile("" : "+v"(an1[0]));
+                asm volatile("" : "+v"(an1[1]));
+                split_of(an1[0], an1[1], pa_s0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
+        // first k-tile of this output tile: its A registers were requested before the previous epilogue (or in the
+        // prologue); split their first half now
+        asm volatile("" : "+v"(a0[0]));
+        asm volatile("" : "+v"(a0[1]));
+        split_of(a0[0], a0[1], pa_s0);
         constexpr std::integral_constant<int, 0> steady{};
         constexpr std::integral_constant<int, 1> tail1{};
         constexpr std::integral_constant<int, 2> tail2{};
         for (int kt = 0; kt < KT - 2; kt += 3) {  // (KT - 2) % 3 == 0 (host check); KT is even, so stage = kt & 1
-            step(steady, kt, kt & 1, a0, a2);
-            step(steady, kt + 1, (kt + 1) & 1, a1, a0);
-            step(steady, kt + 2, kt & 1, a2, a1);
+            step(steady, kt, kt & 1, a0, a1, a2);
+            step(steady, kt + 1, (kt + 1) & 1, a1, a2, a0);
+            step(steady, kt + 2, kt & 1, a2, a0, a1);
         }
-        step(tail1, KT - 2, 0, a0, a2);
-        step(tail2, KT - 1, 1, a1, a2);
+        step(tail1, KT - 2, 0, a0, a1, a2);
+        step(tail2, KT - 1, 1, a1, a2, a2);
 
         // next output tile: its first k-tile lands under the epilogue (the slabs have their own LDS region)
         const unsigned v_next = v + gridDim.x;
@@ -216,11 +228,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
             rows_ok = m0 + wave * 32 < M;
             ga = a_ptr(m0, rows_ok);
         }
-        if (EPI != SCREAM_EPI_RES_LN && has_next) {
-            dma_w(n0, 0, 0);
-            load_a(a0, 0);
-            load_a(a1, 1);
-        }
+        if (EPI != SCREAM_EPI_RES_LN && has_next) request_first();
         if (X3_ABLATE & 1) {
             float keep = 0.f;
 #pragma unroll
@@ -233,11 +241,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
         }
         if (!has_next) break;
         v = v_next;
-        if (EPI == SCREAM_EPI_RES_LN) {
-            dma_w(n0, 0, 0);
-            load_a(a0, 0);
-            load_a(a1, 1);
-        }
+        if (EPI == SCREAM_EPI_RES_LN) request_first();
     }
 }
 
