@@ -10,12 +10,26 @@
 // Same inputs, same outputs, same epilogues and tolerances as gemm_f32.hip; the dtype of the path stays fp32.
 //
 // Geometry: block tile 256 x 256, 512 threads = 8 waves stacked in M (wave tile 32 x 256, 128 accumulator VGPRs), one
-// persistent block per CU.  W is pre-split on the host into three bf16 planes [3][N][K] and staged by LDS-DMA, 32-deep
-// k-tiles, double buffered (2 x 48 KiB; rows are 64 B, 16-byte chunk c of row n lives at c ^ ((n >> 2) & 3) so that
-// the 16 lanes of a ds_read_b128 group cover 16 distinct bank slots).  A stays fp32 in HBM: lane (r, half) streams its
-// 64 contiguous bytes of row r per k-tile straight into registers and splits them there (v_cvt_pk_bf16_f32 + 2 subs per
-// plane).  Lane-half h owns k = 16h + 8s + j of step s for both operands.  A dedicated 64 KiB LDS region holds the
-// epilogue slabs, so the first k-tile of the next output tile is already in flight during the epilogue.
+// persistent block per CU.
+//   * W is split and re-tiled once (scream_pack_w_x3) into an image that is stored k-tile by k-tile exactly as it sits
+//     in LDS: [3 planes][K/32][N][32] bf16, rows of 64 B whose 16-byte chunk c lives at c ^ ((n >> 2) & 3) so that the 16
+//     lanes of a ds_read_b128 group cover 16 distinct bank slots.  A k-tile stage is 48 one-KiB LDS-DMA pieces of
+//     CONTIGUOUS memory (with a plain [N][K] plane every piece touched 16 lines for half their bytes); double buffered.
+//   * A stays fp32 in HBM: lane (r, half) streams its 64 contiguous bytes of row r per k-tile straight into registers
+//     (three register sets, requested TWO k-tiles ahead) and splits them there (v_cvt_pk_bf16_f32 + subtract, twice).
+//     Lane-half h owns k = 16h + 8s + j of step s for both operands.
+//   * One barrier per k-tile with COUNTED waits: requests are issued in a fixed order (D(kt+1), then A(kt+2), pinned
+//     with sched_barrier) so that s_waitcnt vmcnt(4) at the barrier covers the W stage and leaves the A loads of the
+//     k-tile after next in flight; the barrier is followed directly by MFMAs (the first step's operand split was done
+//     at the end of the previous k-tile, the requests go out between the two steps).
+//   * A dedicated 64 KiB LDS region holds the epilogue slabs, so the first k-tile of the next output tile is already
+//     in flight during the epilogue.
+// What was measured and rejected on the way (tools/x3_ablate.py, tools/ubench/, profiles/r01_x3_ablation.txt): two
+// independent 128-row blocks per CU (doubles the W traffic; same speed), one wave per SIMD with 64-row wave tiles and
+// 512 registers (slower: a lone in-order wave does not keep the pipe full), spreading the fragment reads between the
+// MFMAs, starting the CUs out of phase, non-temporal stores.  On this chip a wave that issues MFMAs back to back
+// starves the LDS and vector-memory instructions of the other wave on its SIMD (not its VALU), which is why the
+// k-tile time is close to the SUM of the MFMA, LDS, VMEM and VALU issue times rather than their maximum.
 // Tuning aid (tools/x3_ablate.py builds variants): bit 0 no epilogue, 1 no W DMA after the first k-tile, 2 no A loads
 // after the first, 3 no MFMAs, 4 no LDS fragment reads, 5 no operand split.  Always 0 in libscream_hip.so.
 #ifndef X3_ABLATE
@@ -23,7 +37,6 @@
 #endif
 #include <type_traits>
 
-#include "gemm_epilogue.h"
 #include "gemm_epilogue.h"
 
 namespace {
