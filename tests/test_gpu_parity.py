@@ -62,6 +62,39 @@ def test_gemm_plain_and_activations(M, N, K, kind):
     torch.testing.assert_close(out.double(), (ref + bias.double()).clamp_min(0), rtol=1e-5, atol=2e-5)
 
 
+def test_pack_w_x3_is_an_exact_split():
+    """scream_pack_w_x3: the three bf16 planes sum back to W bit for bit (in fp32 and in fp64), and the image is the
+    documented k-tile-major layout with the 16-byte chunk swizzle (include/scream_hip.h)."""
+    g = torch.Generator().manual_seed(3)
+    N, K = 512, 160
+    W = torch.randn(N, K, generator=g) * torch.logspace(-6, 3, N).unsqueeze(1)  # nine decades of magnitudes
+    img = ops.split_planes(dev(W)).cpu()  # [3, K/32, N, 32]
+    assert img.shape == (3, K // 32, N, 32) and img.dtype == torch.bfloat16
+    n = torch.arange(N)
+    chunk = (torch.arange(4).view(1, 4) ^ ((n >> 2) & 3).view(N, 1))  # stored chunk cs of row n holds logical chunk cs ^ swz
+    planes = torch.empty(3, N, K)
+    for kt in range(K // 32):
+        rows = img[:, kt].float().view(3, N, 4, 8)
+        for cs in range(4):
+            c = chunk[:, cs]
+            for cc in range(4):
+                sel = c == cc
+                planes[:, sel, kt * 32 + cc * 8: kt * 32 + cc * 8 + 8] = rows[:, sel, cs]
+    assert torch.equal((planes[0] + planes[1]) + planes[2], W)
+    assert torch.equal(planes.double().sum(0), W.double())
+    assert torch.equal(planes[0], W.to(torch.bfloat16).float())
+
+
+def test_gemm_x3_rejects_unsupported_k():
+    from scream_amd._lib import ScreamHipError
+    A = torch.zeros(128, 128, device=DEV)
+    with pytest.raises(ScreamHipError):
+        ops.split_planes(torch.zeros(256, 48, device=DEV))  # K % 32
+    Wp = torch.zeros(3, 4, 256, 32, device=DEV, dtype=torch.bfloat16)  # K = 128 is not 64 + 96 j
+    with pytest.raises(ScreamHipError):
+        ops.gemm_x3(A, Wp)
+
+
 @pytest.mark.parametrize("kind", ["f32", "x3"])
 def test_gemm_asymmetric_identity(kind):
     """A = I with an asymmetric W catches a transposed fragment/C map (cdna guide, section 3); exact on both paths
