@@ -11,8 +11,11 @@ of per-pair metric rows when N > 1, the path's only collective).  Rank 0 prints 
 Extra objects on that line:
   roofline     -- the GEMM kernel (all epilogue instantiations pooled; per-instantiation rows in "by_kernel" so
                   they can be matched against profiles/*kernel_stats*): algorithmic fp32 flops (true, unpadded
-                  token counts) / summed launch time, measured live with HIP events on the launch stream inside
-                  the timed region (scream_trace_*).  Peak (MI355X_MICROARCH.md): SCREAM_GEMM=x3 (default) runs
+                  token counts) / the time during which a GEMM launch was running, measured live with HIP events
+                  on the launch streams inside the timed region (scream_trace_*).  The step's pairs run as two
+                  concurrent lanes, so launches overlap: that time is the union of the launch intervals
+                  ("busy_ms_per_step"; "summed_launch_ms_per_step" and the per-launch avg_ms rows count overlapped
+                  time twice and are what rocprofv3's per-kernel durations add up to; --lanes 1 makes them equal).  Peak (MI355X_MICROARCH.md): SCREAM_GEMM=x3 (default) runs
                   gemm_x3_kernel on the bf16 matrix cores with six MFMAs per fp32 product -> 2500 / 6 = 416.7
                   TFLOP/s of fp32-equivalent work; SCREAM_GEMM=f32 runs gemm_f32_kernel against the 157.3
                   TFLOP/s fp32 matrix peak.
@@ -101,6 +104,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per step per GPU")
+    ap.add_argument("--lanes", type=int, default=2, help="concurrent sub-batches of the step's pairs (scream_amd/lanes.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gen-procs", type=int, default=0, help="worker processes for synthetic data (0 = auto)")
     ap.add_argument("--workload", default="3dmatch", choices=["3dmatch", "kitti", "uniform64k"],
@@ -121,7 +125,7 @@ def main():
 
     import torch
     import torch.distributed as tdist
-    from scream_amd import _lib, ops
+    from scream_amd import _lib, lanes, ops
     from scream_amd import dist as sdist
     from scream_amd.evaluate import gt_pose_metric
     from scream_amd.geometry import register_batch
@@ -145,20 +149,34 @@ def main():
     net.load_state_dict(sd)
     net = net.to(dev).eval()
 
-    batch = PackedBatch.from_pairs([it[0].to(dev) for it in items], [it[1].to(dev) for it in items],
-                                   [it[3].reshape(3).to(dev) for it in items])
-    s = torch.tensor([it[4] for it in items], dtype=torch.float32, device=dev)
-    c = torch.stack([it[5] for it in items]).to(dev)
-    T_gt = torch.stack([gt_pose_metric(it[2], it[3], it[4], it[5]) for it in items]).to(dev)
+    # The step's pairs run as concurrent lanes (scream_amd/lanes.py): independent sub-batches on their own HIP streams
+    # whose kernels fill each other's partial last rounds and store-bound epilogues.  Inputs are resident per lane.
+    class Lane:
+        def __init__(self, its):
+            self.batch = PackedBatch.from_pairs([it[0].to(dev) for it in its], [it[1].to(dev) for it in its],
+                                                [it[3].reshape(3).to(dev) for it in its])
+            self.s = torch.tensor([it[4] for it in its], dtype=torch.float32, device=dev)
+            self.c = torch.stack([it[5] for it in its]).to(dev)
+            self.T_gt = torch.stack([gt_pose_metric(it[2], it[3], it[4], it[5]) for it in its]).to(dev)
+
+    lane_parts = [Lane([items[i] for i in rg]) for rg in lanes.split(B, args.lanes)]
+    src_len = [n for ln in lane_parts for n in ln.batch.src_len]
+    tgt_len = [n for ln in lane_parts for n in ln.batch.tgt_len]
+    rows_total = sum(ln.batch.rows_total for ln in lane_parts)
     pair_ids = torch.arange(rank * B, (rank + 1) * B, device=dev, dtype=torch.float32)
     gathered = [torch.empty(B, sdist.ROW_WIDTH, device=coll_dev) for _ in range(world)] if world > 1 else None
 
     dis_thresh = 1.5 if args.workload == "kitti" else 0.1  # evaluate_kitti.py:109 / evaluate_3d_match.py:178
 
+    def lane_step(ln, trace):
+        src_pred = net.forward_packed(ln.batch, trace=trace)                                  # A1-A6
+        T, n_corr, idx, dmin, valid = register_batch(ln.batch, src_pred, ln.s, ln.c, dis_thresh)  # A7-A9
+        re, te = ops.transformation_error_batched(T, ln.T_gt)                                 # A10
+        return re, te, n_corr
+
     def step(trace=None):
-        src_pred = net.forward_packed(batch, trace=trace)                           # A1-A6
-        T, n_corr, idx, dmin, valid = register_batch(batch, src_pred, s, c, dis_thresh)  # A7-A9
-        re, te = ops.transformation_error_batched(T, T_gt)                          # A10
+        outs = lanes.run(dev, lane_parts, lambda ln: lane_step(ln, trace))
+        re, te, n_corr = (torch.cat([o[i] for o in outs]) for i in range(3))
         if world > 1:  # the path's only exchange: per-pair metric rows
             rows = torch.zeros(B, sdist.ROW_WIDTH, device=dev)
             rows[:, 0], rows[:, 4], rows[:, 5] = pair_ids, re, te
@@ -172,7 +190,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    cap = 200 * max(args.steps, 1)
+    cap = 200 * len(lane_parts) * max(args.steps, 1)  # ~135 records per forward
     trace = lib.scream_trace_create(cap)
     assert trace, "scream_trace_create failed"
     fence()
@@ -192,9 +210,18 @@ def main():
     mm = (C.c_int64 * cap)()
     nn = (C.c_int32 * cap)()
     kk = (C.c_int32 * cap)()
+    starts = (C.c_float * cap)()
     cnt = lib.scream_trace_read(trace, cap, ms, kind, mm, nn, kk)
     assert cnt > 0, "trace empty"
+    assert lib.scream_trace_read_starts(trace, cap, starts) == cnt
     lib.scream_trace_destroy(trace)
+    # lanes overlap in time: the GEMM's busy time is the UNION of its launch intervals, not their sum
+    iv = sorted((starts[i], starts[i] + ms[i]) for i in range(cnt) if kind[i] < 100)
+    gemm_busy_ms, hi = 0.0, -1.0
+    for a, b_ in iv:
+        if b_ > hi:
+            gemm_busy_ms += b_ - max(a, hi)
+            hi = b_
     by, by_shape = {}, {}
     for i in range(cnt):
         e = by.setdefault(kind[i], {"launches": 0, "ms": 0.0, "padded_flops": 0.0})
@@ -207,10 +234,10 @@ def main():
             e2["ms"] += ms[i]
     gemm_ms = sum(v["ms"] for k_, v in by.items() if k_ < 100)
     gemm_launches = sum(v["launches"] for k_, v in by.items() if k_ < 100)
-    rows_true = sum(batch.src_len) + sum(batch.tgt_len)
-    pad_eff = rows_true / batch.rows_total
-    algo_flops_step = sum(gemm_flops_per_pair(n, m) for n, m in zip(batch.src_len, batch.tgt_len))
-    achieved = algo_flops_step * args.steps / (gemm_ms * 1e-3) / 1e12
+    rows_true = sum(src_len) + sum(tgt_len)
+    pad_eff = rows_true / rows_total
+    algo_flops_step = sum(gemm_flops_per_pair(n, m) for n, m in zip(src_len, tgt_len))
+    achieved = algo_flops_step * args.steps / (gemm_busy_ms * 1e-3) / 1e12
     by_kernel = []
     for k_, v in sorted(by.items(), key=lambda kv: (kv[0] >= 100, kv[0])):
         row = {"kernel": GEMM_NAMES.get(k_, str(k_)), "launches": v["launches"],
@@ -242,8 +269,8 @@ def main():
                                     "uniform64k": "BASELINE configs[4]: 65 536 uniform points per cloud"}[args.workload]
                                    + ", batch-of-pairs=%d per GPU, A1-A10 per pair (forward 6+6 layers d_model 256, 1-NN thresh %g, "
                                      "Kabsch, RE/TE), random-init weights seed 0" % (B, dis_thresh),
-                       "pairs_per_step_per_gpu": B, "mean_src_points": round(float(np.mean(batch.src_len)), 1),
-                       "mean_tgt_points": round(float(np.mean(batch.tgt_len)), 1), "parallelism": "dp%d (pairs sharded, metric-row all-gather)" % world,
+                       "pairs_per_step_per_gpu": B, "lanes": len(lane_parts), "mean_src_points": round(float(np.mean(src_len)), 1),
+                       "mean_tgt_points": round(float(np.mean(tgt_len)), 1), "parallelism": "dp%d (pairs sharded, metric-row all-gather)" % world,
                        "gemm_backend": net.gemm_backend},
             "roofline": {"bound": "mfma", "kernel": kernel_desc,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -251,6 +278,8 @@ def main():
                          "mfma_tflops_issued": round(achieved * (6 if x3 else 1), 1),
                          "frac_of_fp32_matrix_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
                          "launches": gemm_launches, "avg_ms": round(gemm_ms / gemm_launches, 4),
+                         "busy_ms_per_step": round(gemm_busy_ms / args.steps, 3),
+                         "summed_launch_ms_per_step": round(gemm_ms / args.steps, 3),
                          "algorithmic_gflop_per_step": round(algo_flops_step / 1e9, 1),
                          "row_padding_efficiency": round(pad_eff, 4), "by_kernel": by_kernel,
                          "by_gemm_shape": by_gemm_shape},

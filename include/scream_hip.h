@@ -191,6 +191,10 @@ void scream_trace_destroy(void* trace);
 int scream_trace_reset(void* trace);
 int scream_trace_read(void* trace, int32_t max_records, float* ms, int32_t* kind, int64_t* m,
                       int32_t* n, int32_t* k);
+/* Start of every record in ms after the start of record 0.  One trace may be handed to forwards running on
+ * several streams at once (pairs are independent, so a step can run as concurrent lanes); their records then
+ * overlap in time and the busy time of a kernel class is the union of its intervals, not the sum. */
+int scream_trace_read_starts(void* trace, int32_t max_records, float* start_ms);
 
 /* ---- A7: thresholded 1-NN of every query point in its pair's target cloud.
  * Replaces square_distance(src_pred / s, tgt / s)[0].min(dim=1) and the threshold compare at

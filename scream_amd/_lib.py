@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscream_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -59,6 +59,7 @@ SIGNATURES = {
     "scream_trace_destroy": (None, [V]),
     "scream_trace_reset": (C.c_int, [V]),
     "scream_trace_read": (C.c_int, [V, I32, V, V, V, V, V]),
+    "scream_trace_read_starts": (C.c_int, [V, I32, V]),
     "scream_nn_search": (C.c_int, [V, V, V, V, V, V, V, I32, I32, I32, I64, I64, F32, V, V, V, V, V, V]),
     "scream_square_distance": (C.c_int, [V, V, V, I32, I32, I32, V]),
     "scream_kabsch_corr": (C.c_int, [V, V, V, V, V, V, V, V, V, I32, V, V, V]),

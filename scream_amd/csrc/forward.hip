@@ -151,8 +151,8 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
 
 }  // namespace
 
-extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi5"; }
-extern "C" int scream_abi_version(void) { return 5; }
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi6"; }
+extern "C" int scream_abi_version(void) { return 6; }
 
 extern "C" void* scream_trace_create(int32_t capacity) {
     if (capacity <= 0) return nullptr;
@@ -197,6 +197,15 @@ extern "C" int scream_trace_read(void* trace, int32_t max_records, float* ms, in
         n[i] = t->n[i];
         k[i] = t->k[i];
     }
+    return cnt;
+}
+
+extern "C" int scream_trace_read_starts(void* trace, int32_t max_records, float* start_ms) {
+    SCREAM_REQUIRE(trace && start_ms && max_records >= 0, SCREAM_EINVAL);
+    Trace* t = reinterpret_cast<Trace*>(trace);
+    const int cnt = t->count < max_records ? t->count : max_records;
+    for (int i = 0; i < cnt; ++i)
+        if (hipEventElapsedTime(&start_ms[i], t->ev[0], t->ev[2 * i]) != hipSuccess) return SCREAM_EINVAL;
     return cnt;
 }
 

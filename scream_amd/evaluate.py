@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import dist as sdist
+from . import lanes as _lanes
 from . import ops
 from .data import SCENE_NAMES, collate_pairs
 from .geometry import processbar, register_batch
@@ -96,17 +97,10 @@ def aggregate_rows(rows: np.ndarray, re_static_method: str = "median"):
     return loss, rre / used, rte / used, rr / used
 
 
-@torch.no_grad()
-def register_items(net, its: Sequence[tuple], centers: Sequence[torch.Tensor], pair_ids: Sequence[int],
-                   corr: str = "tgt", dis_thresh: float = 0.1, icp=None, icp_dist: float = ICP_MAX_CORR_DIST,
-                   icp_iters: int = ICP_MAX_ITER, device: Optional[torch.device] = None,
-                   pred_hook: Optional[Callable] = None):
-    """A1-A10 (+ optional ICP) for one batch.  its[i] = (src, tgt, rot, trans, s, c) normalised fp32 CPU tensors;
-    centers[i] = the src_center the evaluator passes to the model.  Returns host arrays
-    (T [B,4,4], T_gt [B,4,4], re [B], te [B], loss [B])."""
-    device = device or next(net.parameters()).device
-    srcs = [it[0].to(device) for it in its]
-    tgts = [it[1].to(device) for it in its]
+def _register_lane(net, its, centers, pair_ids, corr, dis_thresh, icp, icp_dist, icp_iters, device, pred_hook):
+    """Device part of register_items for one lane (runs on the current stream): pack, A1-A6, A7-A9, A10 (+ GPU ICP)."""
+    srcs = [it[0].to(device, non_blocking=True) for it in its]
+    tgts = [it[1].to(device, non_blocking=True) for it in its]
     batch = PackedBatch.from_pairs(srcs, tgts, [cc.reshape(3).to(device) for cc in centers])
     src_pred = net.forward_packed(batch)
     if pred_hook is not None:
@@ -130,6 +124,33 @@ def register_items(net, its: Sequence[tuple], centers: Sequence[torch.Tensor], p
         better = (re2 <= re) & (te2 <= te)
         T = torch.where(better[:, None, None], T2, T)
         re, te = torch.where(better, re2, re), torch.where(better, te2, te)
+    preds = batch.unpack_src(src_pred)
+    loss = torch.stack([net.loss(preds[i][None], srcs[i][None], it[2][None].to(device), it[3][None].to(device))
+                        for i, it in enumerate(its)])
+    return T, T_gt, T_gt_d, re, te, loss
+
+
+@torch.no_grad()
+def register_items(net, its: Sequence[tuple], centers: Sequence[torch.Tensor], pair_ids: Sequence[int],
+                   corr: str = "tgt", dis_thresh: float = 0.1, icp=None, icp_dist: float = ICP_MAX_CORR_DIST,
+                   icp_iters: int = ICP_MAX_ITER, device: Optional[torch.device] = None,
+                   pred_hook: Optional[Callable] = None, lanes: Optional[int] = None):
+    """A1-A10 (+ optional ICP) for one batch.  its[i] = (src, tgt, rot, trans, s, c) normalised fp32 CPU tensors;
+    centers[i] = the src_center the evaluator passes to the model.  Returns host arrays
+    (T [B,4,4], T_gt [B,4,4], re [B], te [B], loss [B]).  The batch runs as `lanes` concurrent sub-batches of pairs
+    (scream_amd/lanes.py; default 2 from 8 pairs up) -- per-pair results do not depend on the split."""
+    device = device or next(net.parameters()).device
+    if lanes is None:
+        lanes = _lanes.DEFAULT_LANES if len(its) >= 8 else 1
+    parts = _lanes.split(len(its), lanes)
+    outs = _lanes.run(device, parts, lambda rg: _register_lane(
+        net, [its[i] for i in rg], [centers[i] for i in rg], [pair_ids[i] for i in rg], corr, dis_thresh, icp, icp_dist,
+        icp_iters, device, pred_hook))
+    T = torch.cat([o[0] for o in outs])
+    T_gt = torch.cat([o[1] for o in outs])
+    T_gt_d = torch.cat([o[2] for o in outs])
+    re, te = torch.cat([o[3] for o in outs]), torch.cat([o[4] for o in outs])
+    loss = torch.cat([o[5] for o in outs]).reshape(-1).cpu().numpy().astype(np.float64)
     T_h, re_h, te_h = T.cpu().numpy(), re.cpu().numpy().astype(np.float64), te.cpu().numpy().astype(np.float64)
     if callable(icp):  # e.g. a wrapper around o3d.registration_icp: (item, T_init) -> T
         for i, it in enumerate(its):
@@ -137,9 +158,6 @@ def register_items(net, its: Sequence[tuple], centers: Sequence[torch.Tensor], p
             r1, t1 = ops.transformation_error_batched(torch.from_numpy(refined[None]).to(device), T_gt_d[i:i + 1].contiguous())
             if r1.item() <= re_h[i] and t1.item() <= te_h[i]:
                 T_h[i], re_h[i], te_h[i] = refined, r1.item(), t1.item()
-    preds = batch.unpack_src(src_pred)
-    loss = np.array([net.loss(preds[i][None], srcs[i][None], it[2][None].to(device), it[3][None].to(device)).item()
-                     for i, it in enumerate(its)])
     return T_h, T_gt.numpy(), re_h, te_h, loss
 
 

@@ -162,8 +162,13 @@ class PointTransformer(nn.Module):
         lib = _lib.load()
         dev = batch.xyz.device
         need = lib.scream_forward_workspace_bytes(batch.rows_src, batch.rows_total, batch.n_pairs, batch.max_chunks)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        # one scratch buffer per stream: concurrent lanes (scream_amd/lanes.py) run forwards of the same model side by side
+        if self._ws is None:
+            self._ws = {}
+        key = (dev, ops._stream())
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[key] = torch.empty(need, device=dev, dtype=torch.uint8)
         bt = _lib.BatchT()
         bt.n_pairs, bt.rows_src, bt.rows_total, bt.max_chunks = batch.n_pairs, batch.rows_src, batch.rows_total, batch.max_chunks
         bt.xyz, bt.center = ops._p(batch.xyz), ops._p(batch.center)
@@ -172,7 +177,7 @@ class PointTransformer(nn.Module):
         bt.cloud_len = ops._p(batch.cloud_len, torch.int32)
         src_pred = torch.empty(batch.rows_src, 3, device=dev, dtype=torch.float32)
         feats = torch.empty(batch.rows_src, D_MODEL, device=dev, dtype=torch.float32) if return_feats else None
-        _lib.check(lib.scream_forward(C.byref(mt), C.byref(bt), self._ws.data_ptr(), self._ws.numel(),
+        _lib.check(lib.scream_forward(C.byref(mt), C.byref(bt), ws.data_ptr(), ws.numel(),
                                       src_pred.data_ptr(), feats.data_ptr() if return_feats else None,
                                       trace, ops._stream()), "scream_forward")
         return (src_pred, feats) if return_feats else src_pred
