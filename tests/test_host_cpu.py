@@ -256,3 +256,13 @@ def test_normalize_pair_matches_oracle_both_modes():
     assert abs(float(ext.max()) - 2.0) < 1e-4
     item = SyntheticPairs("3dmatch", 4, 10)[1]
     assert len(item) == 9 and item[5].tolist() == [0, 2] and item[8] == 11 % 8
+
+
+def test_lane_split_is_a_contiguous_partition():
+    from scream_amd.lanes import split
+    for n in (1, 2, 7, 8, 32, 33):
+        for lanes in (1, 2, 3, 4, 40):
+            parts = split(n, lanes)
+            assert len(parts) == min(lanes, n) and all(len(p) > 0 for p in parts)
+            assert [i for p in parts for i in p] == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
