@@ -39,6 +39,20 @@
 
 #include "gemm_epilogue.h"
 
+#ifdef X3_STAMPS  // tuning aid: s_memtime stamps of one output tile per block (tools/x3_stamps.py)
+__device__ long long x3_stamps[256 * 8 * 160];
+extern "C" int scream_x3_stamps_read(long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(x3_stamps), sizeof(long long) * 256 * 8 * 160);
+}
+#define STAMP(slot)                                                                                    \
+    do {                                                                                               \
+        if (stamp_on && lane == 0 && (slot) < 160)                                                      \
+            x3_stamps[((int)blockIdx.x * 8 + wave) * 160 + (slot)] = __builtin_amdgcn_s_memtime();     \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -136,7 +150,15 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
     request_first();
 
     bf16x8 pa_s0[3];  // split planes of the first 16-deep step of the k-tile about to be computed
+#ifdef X3_STAMPS
+    int tile_no = 0;
+#endif
     for (;;) {
+#ifdef X3_STAMPS
+        const bool stamp_on = tile_no == 2 && blockIdx.x < 256;
+        ++tile_no;
+        STAMP(0);
+#endif
         f32x16 acc[8];
 #pragma unroll
         for (int tn = 0; tn < 8; ++tn)
@@ -190,12 +212,15 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
             constexpr int TAIL = decltype(tail)::value;
             // everything but the four youngest operations (A(kt+1)) has landed: W k-tile kt is in LDS for every wave,
             // and every wave is done reading the other stage
+            STAMP(4 + kt * 4 + 0);
             if (TAIL <= 1) ring_barrier<4>(); else ring_barrier<0>();
+            STAMP(4 + kt * 4 + 1);
             const char* wb = smem + stage * STAGE_BYTES;
             bf16x8 fb[2][3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) fb[0][p] = *reinterpret_cast<const bf16x8*>(wb + p * PLANE_BYTES + boff[0]);
             groups(wb, 0, pa_s0, fb);
+            STAMP(4 + kt * 4 + 2);
             if (TAIL <= 1 && !(X3_ABLATE & 2)) dma_w(n0, stage ^ 1, kt + 1);
             __builtin_amdgcn_sched_barrier(0);  // the counted waits rely on this issue order: D(kt+1), then A(kt+2)
             if (TAIL == 0 && !(X3_ABLATE & 4)) load_a(an2, kt + 2);
@@ -204,6 +229,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
             split_of(ac[2], ac[3], pa_s1);
             __builtin_amdgcn_sched_barrier(0);
             groups(wb, 1, pa_s1, fb);
+            STAMP(4 + kt * 4 + 3);
             if (TAIL <= 1) {  // A(kt+1) is older than what was requested above: wait for it alone, split its first half
                 if (TAIL == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 10); else __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
                 asm volatile("" : "+v"(an1[0]));
@@ -228,6 +254,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
         step(tail1, KT - 2, 0, a0, a1, a2);
         step(tail2, KT - 1, 1, a1, a2, a2);
 
+        STAMP(1);
         // next output tile: its first k-tile lands under the epilogue (the slabs have their own LDS region)
         const unsigned v_next = v + gridDim.x;
         const bool has_next = v_next < total_tiles;
@@ -252,6 +279,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
         } else {
             gemm_epilogue<EPI, XWAVES>(acc, slabs, wave, lane, tid, rows_cur, m0_cur, n0_cur, ep, C, ldc);
         }
+        STAMP(2);
         if (!has_next) break;
         v = v_next;
         if (EPI == SCREAM_EPI_RES_LN) request_first();
