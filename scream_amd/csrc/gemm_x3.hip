@@ -22,8 +22,14 @@
 //     with sched_barrier) so that s_waitcnt vmcnt(4) at the barrier covers the W stage and leaves the A loads of the
 //     k-tile after next in flight; the barrier is followed directly by MFMAs (the first step's operand split was done
 //     at the end of the previous k-tile, the requests go out between the two steps).
+//   * The A loads are plain inline asm: hipcc's own vmcnt bookkeeping cannot count across the epilogue's stores and
+//     the loop back edge and would wait for vmcnt(0).  The first barrier of an output tile leaves the previous
+//     epilogue's stores in flight (vmcnt(4 + their number)).
+//   * The two waves of a SIMD are not symmetric: the older one gets the matrix pipe first (s_memtime stamps,
+//     tools/x3_stamps.py: 1.8 k cycles for its first 48 MFMAs against 3.8 k for the younger wave's), so the younger
+//     waves (4-7) do their operand split AFTER the barrier, where they would be starved anyway, the older ones before.
 //   * A dedicated 64 KiB LDS region holds the epilogue slabs, so the first k-tile of the next output tile is already
-//     in flight during the epilogue.
+//     in flight during the epilogue (for every epilogue kind).
 // What was measured and rejected on the way (tools/x3_ablate.py, tools/ubench/, profiles/r01_x3_ablation.txt): two
 // independent 128-row blocks per CU (doubles the W traffic; same speed), one wave per SIMD with 64-row wave tiles and
 // 512 registers (slower: a lone in-order wave does not keep the pipe full), spreading the fragment reads between the
@@ -133,9 +139,15 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
     // A registers: three sets, requested TWO k-tiles ahead (activations that only one output tile reads come from
     // HBM: one k-tile of lead did not cover that latency, profiles/r01_x3_ablation.txt)
     f32x4 a0[4], a1[4], a2[4];
+    // Plain inline-asm loads, on purpose: hipcc's own vmcnt bookkeeping cannot count across the epilogue's stores and
+    // the loop back edge and falls back to vmcnt(0) in front of the first use of these registers.  Every use below
+    // sits behind an explicit counted s_waitcnt followed by an empty asm on the register (which pins the order).
     auto load_a = [&](f32x4 (&a)[4], int kt) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = ld4(ga + kt * XBK + j * 4);
+        const float* p = ga + kt * XBK;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[0]) : "v"(p));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(a[1]) : "v"(p));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(a[2]) : "v"(p));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(a[3]) : "v"(p));
     };
     // issue order D(0), A(0), A(1): the first barrier's vmcnt(4) must leave exactly A(1) in flight
     auto request_first = [&]() {
@@ -150,6 +162,8 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
     request_first();
 
     bf16x8 pa_s0[3];  // split planes of the first 16-deep step of the k-tile about to be computed
+    const bool late = wave >= 4;  // the second wave of each SIMD
+    int first_younger = 0;
 #ifdef X3_STAMPS
     int tile_no = 0;
 #endif
@@ -208,13 +222,29 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
                 split3(lo, hi, pa[0], pa[1], pa[2]);
             }
         };
-        auto step = [&](auto tail, int kt, int stage, f32x4 (&ac)[4], f32x4 (&an1)[4], f32x4 (&an2)[4]) {
+        // wait for everything but the n youngest vector-memory operations of this wave, then the workgroup barrier
+        auto first_barrier = [&]() {
+            if (first_younger == 32) ring_barrier<36>();
+            else if (first_younger == 16) ring_barrier<20>();
+            else ring_barrier<4>();
+        };
+        auto step = [&](auto tail, auto first, int kt, int stage, f32x4 (&ac)[4], f32x4 (&an1)[4], f32x4 (&an2)[4]) {
             constexpr int TAIL = decltype(tail)::value;
-            // everything but the four youngest operations (A(kt+1)) has landed: W k-tile kt is in LDS for every wave,
-            // and every wave is done reading the other stage
+            constexpr bool FIRST = decltype(first)::value;
+            // Everything but the four youngest operations (A(kt+1)) has landed: W k-tile kt is in LDS for every wave
+            // and every wave is done reading the other stage.  On the first k-tile of an output tile the stores of the
+            // previous epilogue are younger still and are left in flight as well (first_younger of them at least).
             STAMP(4 + kt * 4 + 0);
-            if (TAIL <= 1) ring_barrier<4>(); else ring_barrier<0>();
+            if (FIRST) first_barrier();
+            else if (TAIL <= 1) ring_barrier<4>();
+            else ring_barrier<0>();
             STAMP(4 + kt * 4 + 1);
+            if (FIRST || late) {  // the younger waves of each SIMD split their first half here: they would only be
+                asm volatile("" : "+v"(ac[0]));  // starved by the older wave's MFMAs for that long anyway, and the
+                asm volatile("" : "+v"(ac[1]));  // barrier is released that much earlier
+                split_of(ac[0], ac[1], pa_s0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const char* wb = smem + stage * STAGE_BYTES;
             bf16x8 fb[2][3];
 #pragma unroll
@@ -226,11 +256,13 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
             if (TAIL == 0 && !(X3_ABLATE & 4)) load_a(an2, kt + 2);
             __builtin_amdgcn_sched_barrier(0);
             bf16x8 pa_s1[3];
+            asm volatile("" : "+v"(ac[2]));
+            asm volatile("" : "+v"(ac[3]));
             split_of(ac[2], ac[3], pa_s1);
             __builtin_amdgcn_sched_barrier(0);
             groups(wb, 1, pa_s1, fb);
             STAMP(4 + kt * 4 + 3);
-            if (TAIL <= 1) {  // A(kt+1) is older than what was requested above: wait for it alone, split its first half
+            if (TAIL <= 1 && !late) {  // A(kt+1) is older than what was requested above: wait for it alone, split its first half
                 if (TAIL == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 10); else __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
                 asm volatile("" : "+v"(an1[0]));
                 asm volatile("" : "+v"(an1[1]));
@@ -238,21 +270,25 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        // first k-tile of this output tile: its A registers were requested before the previous epilogue (or in the
-        // prologue); split their first half now
-        asm volatile("" : "+v"(a0[0]));
-        asm volatile("" : "+v"(a0[1]));
-        split_of(a0[0], a0[1], pa_s0);
         constexpr std::integral_constant<int, 0> steady{};
         constexpr std::integral_constant<int, 1> tail1{};
         constexpr std::integral_constant<int, 2> tail2{};
-        for (int kt = 0; kt < KT - 2; kt += 3) {  // (KT - 2) % 3 == 0 (host check); KT is even, so stage = kt & 1
-            step(steady, kt, kt & 1, a0, a1, a2);
-            step(steady, kt + 1, (kt + 1) & 1, a1, a2, a0);
-            step(steady, kt + 2, kt & 1, a2, a0, a1);
+        constexpr std::integral_constant<bool, true> first{};
+        constexpr std::integral_constant<bool, false> later{};
+        if (KT > 2) {  // (KT - 2) % 3 == 0 (host check); KT is even, so stage = kt & 1
+            step(steady, first, 0, 0, a0, a1, a2);
+            step(steady, later, 1, 1, a1, a2, a0);
+            step(steady, later, 2, 0, a2, a0, a1);
+            for (int kt = 3; kt < KT - 2; kt += 3) {
+                step(steady, later, kt, kt & 1, a0, a1, a2);
+                step(steady, later, kt + 1, (kt + 1) & 1, a1, a2, a0);
+                step(steady, later, kt + 2, kt & 1, a2, a0, a1);
+            }
+            step(tail1, later, KT - 2, 0, a0, a1, a2);
+        } else {
+            step(tail1, first, 0, 0, a0, a1, a2);
         }
-        step(tail1, KT - 2, 0, a0, a1, a2);
-        step(tail2, KT - 1, 1, a1, a2, a2);
+        step(tail2, later, KT - 1, 1, a1, a2, a2);
 
         STAMP(1);
         // next output tile: its first k-tile lands under the epilogue (the slabs have their own LDS region)
@@ -268,7 +304,9 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
             rows_ok = m0 + wave * 32 < M;
             ga = a_ptr(m0, rows_ok);
         }
-        if (EPI != SCREAM_EPI_RES_LN && has_next) request_first();
+        if (has_next) request_first();
+        // vector-memory operations this wave is about to issue behind that request, at least (see first_barrier)
+        first_younger = (X3_ABLATE != 0 || !rows_cur) ? 0 : (EPI == SCREAM_EPI_QKV && n0_cur >= ep.n_act) ? 16 : 32;
         if (X3_ABLATE & 1) {
             float keep = 0.f;
 #pragma unroll
@@ -282,7 +320,6 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
         STAMP(2);
         if (!has_next) break;
         v = v_next;
-        if (EPI == SCREAM_EPI_RES_LN) request_first();
     }
 }
 
