@@ -203,3 +203,28 @@ def test_concurrent_lanes_do_not_change_results():
             out = register_items(net, core, centers, list(range(9)), "tgt", 0.1, "gpu", lanes=lanes)
             for a, b in zip(ref, out):
                 np.testing.assert_array_equal(a, b)
+
+
+def test_open_gf_dem_evaluation_vs_oracle():
+    """evaluate_open_gf.py:46-73 for DEMTransformer: batched forward + fused-search Chamfer + height errors against the
+    oracle's per-sample restatement (dense N x M Chamfer, one sample per forward)."""
+    from models.pointnet import DEMTransformer
+    from scream_amd.evaluate_open_gf import SyntheticDEM, evaluate_dem_generation, evaluate_samples
+    net = DEMTransformer(256, 1, 1)
+    sd = make_state_dict(6, 256, 1, 1, dem=True)
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    ds = SyntheticDEM(3, seed0=11, points=900)
+    rows = evaluate_samples(net, [ds[i] for i in range(3)])
+    want = np.zeros((3, 3))
+    for i in range(3):
+        dsm, coarse, dem, _ = ds[i]
+        assert dsm.shape == dem.shape and 4 <= coarse.shape[0] < dem.shape[0]
+        pred = O.dem_transformer_forward(dsm[None], coarse[None], sd)
+        dist = O.square_distance(pred, dem[None])
+        want[i, 0] = (dist.min(dim=2)[0].mean() + dist.min(dim=1)[0].mean()).item() * 1000
+        dz = pred[0, :, 2] - dem[:, 2]
+        want[i, 1], want[i, 2] = dz.abs().mean().item() * 1000, (dz * dz).mean().item() * 1000
+    np.testing.assert_allclose(rows, want, rtol=2e-4, atol=1e-4)
+    out = evaluate_dem_generation(net, ds, batch_samples=2, verbose=False)
+    np.testing.assert_allclose(out, rows.mean(axis=0), rtol=1e-9)

@@ -266,3 +266,21 @@ def test_lane_split_is_a_contiguous_partition():
             assert len(parts) == min(lanes, n) and all(len(p) > 0 for p in parts)
             assert [i for p in parts for i in p] == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_open_gf_voxel_down_sample_and_sample_layout():
+    from scream_amd.evaluate_open_gf import SyntheticDEM, voxel_down_sample
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(0, 100, size=(5000, 3))
+    out = voxel_down_sample(pts, 20.0)
+    origin = pts.min(axis=0) - 10.0
+    keys = np.floor((pts - origin) / 20.0).astype(np.int64)
+    assert out.shape[0] == len({tuple(k) for k in keys})
+    np.testing.assert_allclose(out.mean(axis=0) * 0 + np.sort(np.floor((out - origin) / 20.0).astype(np.int64), axis=0),
+                               np.sort(np.unique(keys, axis=0), axis=0))  # every centroid lies in its own voxel
+    k0 = keys[0]
+    np.testing.assert_allclose(out[(np.floor((out - origin) / 20.0).astype(np.int64) == k0).all(axis=1)][0],
+                               pts[(keys == k0).all(axis=1)].mean(axis=0))
+    dsm, coarse, dem, c = SyntheticDEM(1, seed0=3, points=500)[0]
+    assert dsm.dtype == torch.float32 and dsm.shape == dem.shape == (500, 3) and coarse.shape[1] == 3
+    assert torch.equal(dsm[:, :2], dem[:, :2]) and (dsm[:, 2] >= dem[:, 2] - 1e-6).all()
