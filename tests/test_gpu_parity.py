@@ -432,3 +432,37 @@ def test_dem_transformer_vs_reference_golden(golden, backend):
         dist = O.square_distance(dem_.cpu(), gt)
         want = dist.min(dim=2)[0].mean() + dist.min(dim=1)[0].mean()
         torch.testing.assert_close(chamfer_distance(dem_, dev(gt)).cpu(), want, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("epi", ["relu", "res_ln", "qkv"])
+def test_gemm_x3_persistent_blocks_many_tiles(epi):
+    """Every block of the persistent x3 grid walks >= 3 output tiles (plus a ragged last round and a trailing 128-row
+    half tile): the counted waits across tile boundaries (next tile requested before the epilogue, its first barrier
+    leaving the epilogue's stores in flight) must hold for every epilogue kind.  Checked against the fp32-MFMA kernel."""
+    M = 256 * 256 * 3 + 37 * 256 + 128
+    g = torch.Generator(device=DEV).manual_seed(11)
+    A = torch.randn(M, 256, device=DEV, generator=g)
+    if epi == "relu":
+        W = torch.randn(256, 256, device=DEV, generator=g) / 16
+        a = ops.gemm_x3(A, ops.split_planes(W), ops.EPI_RELU)
+        b = ops.gemm_f32(A, W, ops.EPI_RELU)
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-5)
+    elif epi == "res_ln":
+        W = torch.randn(256, 256, device=DEV, generator=g) / 16
+        res = torch.randn(M, 256, device=DEV, generator=g)
+        gam, bet = torch.randn(256, device=DEV, generator=g), torch.randn(256, device=DEV, generator=g)
+        a = ops.gemm_x3(A, ops.split_planes(W), ops.EPI_RES_LN, residual=res, gamma=gam, beta=bet)
+        b = ops.gemm_f32(A, W, ops.EPI_RES_LN, residual=res, gamma=gam, beta=bet)
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+    else:
+        W = torch.randn(768, 256, device=DEV, generator=g) / 16
+        n_clouds = M // 128 // 8 + 1  # clouds of up to 8 tiles (1024 rows), the last one shorter
+        tiles = M // 128
+        tile_cloud = torch.arange(tiles, dtype=torch.int32, device=DEV) // 8
+        crow0 = (torch.arange(n_clouds, dtype=torch.int32, device=DEV) * 1024)
+        clen = torch.full((n_clouds,), 1000, dtype=torch.int32, device=DEV)
+        clen[-1] = min(1000, M - int(crow0[-1]))
+        qa, pa = ops.gemm_qkv(A, ops.split_planes(W), 256, tile_cloud, crow0, clen, 0)
+        qb, pb = ops.gemm_qkv(A, W, 256, tile_cloud, crow0, clen, 0)
+        torch.testing.assert_close(qa, qb, rtol=1e-5, atol=2e-5)
+        torch.testing.assert_close(pa, pb, rtol=1e-4, atol=2e-3)  # sums of 128 products of O(1) terms
