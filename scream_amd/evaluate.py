@@ -26,7 +26,7 @@ from . import lanes as _lanes
 from . import ops
 from .data import SCENE_NAMES, collate_pairs
 from .geometry import processbar, register_batch
-from .packing import PackedBatch
+from .packing import PackedBatch, StagingBuffers
 
 
 ICP_MAX_CORR_DIST = 0.1  # evaluate_3d_match.py:111 (metres; KITTI uses 1 and 1000 iterations, evaluate_kitti.py:64-70)
@@ -97,19 +97,31 @@ def aggregate_rows(rows: np.ndarray, re_static_method: str = "median"):
     return loss, rre / used, rte / used, rr / used
 
 
+_staging = {}  # (device, lane stream) -> StagingBuffers
+
+
 def _register_lane(net, its, centers, pair_ids, corr, dis_thresh, icp, icp_dist, icp_iters, device, pred_hook):
-    """Device part of register_items for one lane (runs on the current stream): pack, A1-A6, A7-A9, A10 (+ GPU ICP)."""
-    srcs = [it[0].to(device, non_blocking=True) for it in its]
-    tgts = [it[1].to(device, non_blocking=True) for it in its]
-    batch = PackedBatch.from_pairs(srcs, tgts, [cc.reshape(3).to(device) for cc in centers])
+    """Device part of register_items for one lane (runs on the current stream): pack, A1-A6, A7-A9, A10 (+ GPU ICP).
+    Nothing here blocks the host: the batch and every per-pair scalar go up in two asynchronous copies from pinned
+    memory (a pageable copy or a torch.tensor(..., device=) would wait for everything already queued on the stream)."""
+    B = len(its)
+    T_gt = torch.stack([gt_pose_metric(it[2], it[3], it[4], it[5]) for it in its])
+    extra = np.concatenate([np.array([it[4] for it in its], dtype=np.float32),                       # s      [B]
+                            torch.stack([it[5].reshape(3) for it in its]).numpy().reshape(-1),        # c      [B,3]
+                            T_gt.numpy().astype(np.float32).reshape(-1),                              # T_gt   [B,4,4]
+                            torch.stack([it[2].reshape(3, 3) for it in its]).numpy().reshape(-1),     # rot    [B,3,3]
+                            torch.stack([it[3].reshape(3) for it in its]).numpy().reshape(-1)])       # trans  [B,3]
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    stg = _staging.setdefault(key, StagingBuffers())
+    batch, ex = PackedBatch.from_host([it[0] for it in its], [it[1] for it in its], centers, device, extra, stg)
+    stg.uploaded()
+    s, c = ex[:B], ex[B:4 * B].view(B, 3)
+    T_gt_d = ex[4 * B:20 * B].view(B, 4, 4)
+    rot_d, trans_d = ex[20 * B:29 * B].view(B, 3, 3), ex[29 * B:32 * B].view(B, 3, 1)
     src_pred = net.forward_packed(batch)
     if pred_hook is not None:
         src_pred = pred_hook(batch, src_pred, pair_ids)
-    s = torch.tensor([it[4] for it in its], dtype=torch.float32, device=device)
-    c = torch.stack([it[5] for it in its]).to(device)
     T, n_corr, idx, dmin, valid = register_batch(batch, src_pred, s, c, dis_thresh, corr)
-    T_gt = torch.stack([gt_pose_metric(it[2], it[3], it[4], it[5]) for it in its])
-    T_gt_d = T_gt.to(device)
     re, te = ops.transformation_error_batched(T, T_gt_d)
     if isinstance(icp, str):
         if icp != "gpu":
@@ -125,20 +137,19 @@ def _register_lane(net, its, centers, pair_ids, corr, dis_thresh, icp, icp_dist,
         T = torch.where(better[:, None, None], T2, T)
         re, te = torch.where(better, re2, re), torch.where(better, te2, te)
     preds = batch.unpack_src(src_pred)
-    loss = torch.stack([net.loss(preds[i][None], srcs[i][None], it[2][None].to(device), it[3][None].to(device))
-                        for i, it in enumerate(its)])
+    srcs = batch.unpack_src(batch.xyz[: batch.rows_src])
+    loss = torch.stack([net.loss(preds[i][None], srcs[i][None], rot_d[i:i + 1], trans_d[i:i + 1]) for i in range(B)])
     return T, T_gt, T_gt_d, re, te, loss
 
 
 @torch.no_grad()
-def register_items(net, its: Sequence[tuple], centers: Sequence[torch.Tensor], pair_ids: Sequence[int],
-                   corr: str = "tgt", dis_thresh: float = 0.1, icp=None, icp_dist: float = ICP_MAX_CORR_DIST,
-                   icp_iters: int = ICP_MAX_ITER, device: Optional[torch.device] = None,
-                   pred_hook: Optional[Callable] = None, lanes: Optional[int] = None):
-    """A1-A10 (+ optional ICP) for one batch.  its[i] = (src, tgt, rot, trans, s, c) normalised fp32 CPU tensors;
-    centers[i] = the src_center the evaluator passes to the model.  Returns host arrays
-    (T [B,4,4], T_gt [B,4,4], re [B], te [B], loss [B]).  The batch runs as `lanes` concurrent sub-batches of pairs
-    (scream_amd/lanes.py; default 2 from 8 pairs up) -- per-pair results do not depend on the split."""
+def register_items_async(net, its: Sequence[tuple], centers: Sequence[torch.Tensor], pair_ids: Sequence[int],
+                         corr: str = "tgt", dis_thresh: float = 0.1, icp=None, icp_dist: float = ICP_MAX_CORR_DIST,
+                         icp_iters: int = ICP_MAX_ITER, device: Optional[torch.device] = None,
+                         pred_hook: Optional[Callable] = None, lanes: Optional[int] = None) -> Callable[[], tuple]:
+    """Enqueue A1-A10 (+ optional GPU ICP) for one batch and return ``finish()``, which waits for the device and gives
+    the host arrays of register_items.  Everything between the call and ``finish()`` overlaps the GPU work, which is
+    how evaluate_loader hides the host side of batch i-1 and the packing of batch i+1 behind batch i."""
     device = device or next(net.parameters()).device
     if lanes is None:
         lanes = _lanes.DEFAULT_LANES if len(its) >= 8 else 1
@@ -150,15 +161,62 @@ def register_items(net, its: Sequence[tuple], centers: Sequence[torch.Tensor], p
     T_gt = torch.cat([o[1] for o in outs])
     T_gt_d = torch.cat([o[2] for o in outs])
     re, te = torch.cat([o[3] for o in outs]), torch.cat([o[4] for o in outs])
-    loss = torch.cat([o[5] for o in outs]).reshape(-1).cpu().numpy().astype(np.float64)
-    T_h, re_h, te_h = T.cpu().numpy(), re.cpu().numpy().astype(np.float64), te.cpu().numpy().astype(np.float64)
-    if callable(icp):  # e.g. a wrapper around o3d.registration_icp: (item, T_init) -> T
+    loss = torch.cat([o[5] for o in outs]).reshape(-1)
+    # one small device buffer -> one asynchronous D2H copy into pinned memory
+    flat = torch.cat([T.reshape(-1), re, te, loss]).float()
+    host = torch.empty(flat.shape, dtype=torch.float32, pin_memory=True)
+    host.copy_(flat, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(device))
+    keep = [outs, flat]  # lane-stream allocations stay referenced until the copy has been consumed
+
+    def finish():
+        done.synchronize()
+        B = len(its)
+        h = host.numpy().astype(np.float64)
+        T_h = h[:16 * B].reshape(B, 4, 4).astype(np.float32)
+        re_h, te_h, loss_h = h[16 * B:17 * B].copy(), h[17 * B:18 * B].copy(), h[18 * B:19 * B].copy()
+        if callable(icp):  # e.g. a wrapper around o3d.registration_icp: (item, T_init) -> T
+            for i, it in enumerate(its):
+                refined = np.asarray(icp(it, T_h[i]), dtype=np.float32)
+                r1, t1 = ops.transformation_error_batched(torch.from_numpy(refined[None]).to(device), T_gt_d[i:i + 1].contiguous())
+                if r1.item() <= re_h[i] and t1.item() <= te_h[i]:
+                    T_h[i], re_h[i], te_h[i] = refined, r1.item(), t1.item()
+        keep.clear()
+        return T_h, T_gt.numpy(), re_h, te_h, loss_h
+
+    return finish
+
+
+def register_items(net, its: Sequence[tuple], centers: Sequence[torch.Tensor], pair_ids: Sequence[int],
+                   corr: str = "tgt", dis_thresh: float = 0.1, icp=None, icp_dist: float = ICP_MAX_CORR_DIST,
+                   icp_iters: int = ICP_MAX_ITER, device: Optional[torch.device] = None,
+                   pred_hook: Optional[Callable] = None, lanes: Optional[int] = None):
+    """A1-A10 (+ optional ICP) for one batch.  its[i] = (src, tgt, rot, trans, s, c) normalised fp32 CPU tensors;
+    centers[i] = the src_center the evaluator passes to the model.  Returns host arrays
+    (T [B,4,4], T_gt [B,4,4], re [B], te [B], loss [B]).  The batch runs as `lanes` concurrent sub-batches of pairs
+    (scream_amd/lanes.py; default 2 from 8 pairs up) -- per-pair results do not depend on the split."""
+    return register_items_async(net, its, centers, pair_ids, corr, dis_thresh, icp, icp_dist, icp_iters, device,
+                                pred_hook, lanes)()
+
+
+def evaluate_items_async(net, items: Sequence[tuple], pair_ids: Sequence[int], corr: str = "tgt", dis_thresh: float = 0.1,
+                         icp=None, device: Optional[torch.device] = None, pred_hook: Optional[Callable] = None):
+    """Enqueue one 3DMatch-family batch (items are the reference's 9-tuples); returns ``finish() -> rows [B, 8]``."""
+    its = [_strip(it) for it in items]
+    core = [(it[0], it[1], it[2], it[3], it[4], it[7]) for it in its]
+    centers = [it[3] for it in its]  # src_center = trans^T, evaluate_3d_match.py:84
+    fin = register_items_async(net, core, centers, pair_ids, corr, dis_thresh, icp, device=device, pred_hook=pred_hook)
+
+    def finish():
+        T_h, T_gt, re_h, te_h, loss = fin()
+        rows = np.zeros((len(its), sdist.ROW_WIDTH), dtype=np.float64)
         for i, it in enumerate(its):
-            refined = np.asarray(icp(it, T_h[i]), dtype=np.float32)
-            r1, t1 = ops.transformation_error_batched(torch.from_numpy(refined[None]).to(device), T_gt_d[i:i + 1].contiguous())
-            if r1.item() <= re_h[i] and t1.item() <= te_h[i]:
-                T_h[i], re_h[i], te_h[i] = refined, r1.item(), t1.item()
-    return T_h, T_gt.numpy(), re_h, te_h, loss
+            rmse = math.sqrt(max(RMSE(np.linalg.inv(T_gt[i]) @ T_h[i], it[6]), 0.0))  # evaluate_3d_match.py:122
+            rows[i] = [pair_ids[i], it[8], float(abs(it[5][1] - it[5][0]) > 1), float(rmse < 0.2), re_h[i], te_h[i], rmse, loss[i]]
+        return rows
+
+    return finish
 
 
 def evaluate_items(net, items: Sequence[tuple], pair_ids: Sequence[int], corr: str = "tgt", dis_thresh: float = 0.1,
@@ -166,16 +224,7 @@ def evaluate_items(net, items: Sequence[tuple], pair_ids: Sequence[int], corr: s
     """One 3DMatch-family batch: items are the reference's 9-tuples.  Returns metric rows [B, 8] (dist.ROW_WIDTH).
     pred_hook(batch, src_pred, pair_ids) -> src_pred may replace the network's prediction (used for the
     "registered src + noise" throughput/metric variant of SURVEY.md section 8d and by the parity tests)."""
-    its = [_strip(it) for it in items]
-    core = [(it[0], it[1], it[2], it[3], it[4], it[7]) for it in its]
-    centers = [it[3] for it in its]  # src_center = trans^T, evaluate_3d_match.py:84
-    T_h, T_gt, re_h, te_h, loss = register_items(net, core, centers, pair_ids, corr, dis_thresh, icp, device=device,
-                                                 pred_hook=pred_hook)
-    rows = np.zeros((len(its), sdist.ROW_WIDTH), dtype=np.float64)
-    for i, it in enumerate(its):
-        rmse = math.sqrt(max(RMSE(np.linalg.inv(T_gt[i]) @ T_h[i], it[6]), 0.0))  # evaluate_3d_match.py:122
-        rows[i] = [pair_ids[i], it[8], float(abs(it[5][1] - it[5][0]) > 1), float(rmse < 0.2), re_h[i], te_h[i], rmse, loss[i]]
-    return rows
+    return evaluate_items_async(net, items, pair_ids, corr, dis_thresh, icp, device, pred_hook)()
 
 
 def evaluate_loader(net, loader: Iterable, corr: str = "tgt", dis_thresh: float = 0.1,
@@ -195,15 +244,24 @@ def evaluate_loader(net, loader: Iterable, corr: str = "tgt", dis_thresh: float 
     batches = torch.utils.data.DataLoader(torch.utils.data.Subset(dataset, mine), batch_size=batch_pairs, shuffle=False,
                                           collate_fn=collate_pairs, num_workers=num_workers,
                                           pin_memory=num_workers > 0 and torch.cuda.is_available())
-    for items in batches:
-        ids = mine[done:done + len(items)]
-        r = evaluate_items(net, items, ids, corr, dis_thresh, icp, pred_hook=pred_hook)
+    def collect(finish, n_done):
+        r = finish()
         rows.append(r)
-        done += len(ids)
         if verbose and rank == 0:
             print("\r%s  re: %.5f  te: %.5f  rmse: %.5f  rr: %.5f" % (
-                processbar(done, len(mine)), r[-1, sdist.COL_RE], r[-1, sdist.COL_TE], r[-1, sdist.COL_RMSE],
+                processbar(n_done, len(mine)), r[-1, sdist.COL_RE], r[-1, sdist.COL_TE], r[-1, sdist.COL_RMSE],
                 float(np.concatenate(rows)[:, sdist.COL_SUCCESS].mean())), end="")
+
+    pending = None  # batch i is enqueued before the host side of batch i-1 runs: the GPU never waits for the host
+    for items in batches:
+        ids = mine[done:done + len(items)]
+        fin = evaluate_items_async(net, items, ids, corr, dis_thresh, icp, pred_hook=pred_hook)
+        if pending is not None:
+            collect(*pending)
+        done += len(ids)
+        pending = (fin, done)
+    if pending is not None:
+        collect(*pending)
     local = np.concatenate(rows) if rows else np.zeros((0, sdist.ROW_WIDTH))
     allrows = sdist.all_gather_rows(local)
     out = aggregate_rows(allrows, re_static_method)

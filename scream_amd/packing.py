@@ -17,6 +17,34 @@ import torch
 from .ops import KV_CHUNK, ROW_TILE
 
 
+class StagingBuffers:
+    """Two alternating pairs of pinned host buffers (float32, int32): the asynchronous upload of batch i may still be
+    reading one pair while batch i+1 is packed into the other; a pair is reused only after its upload event."""
+
+    def __init__(self):
+        self._slots = [[None, None, None], [None, None, None]]
+        self._next = 0
+
+    def take(self, n_float: int, n_int: int):
+        slot = self._slots[self._next]
+        self._next ^= 1
+        if slot[2] is not None:
+            slot[2].synchronize()
+        if slot[0] is None or slot[0].numel() < n_float:
+            slot[0] = torch.empty(max(n_float, 1) * 5 // 4, dtype=torch.float32, pin_memory=torch.cuda.is_available())
+        if slot[1] is None or slot[1].numel() < n_int:
+            slot[1] = torch.empty(max(n_int, 1) * 5 // 4, dtype=torch.int32, pin_memory=torch.cuda.is_available())
+        if torch.cuda.is_available():
+            slot[2] = torch.cuda.Event()
+        self._last = slot
+        return slot[0], slot[1]
+
+    def uploaded(self):
+        """Call after the copies that read the last taken buffers have been enqueued (on the current stream)."""
+        if torch.cuda.is_available() and self._last[2] is not None:
+            self._last[2].record()
+
+
 def _round_up(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
@@ -74,6 +102,44 @@ class PackedBatch:
         return cls(B, src_len, tgt_len, row0, lens, rows_src, rows_total, max_chunks, xyz, center,
                    torch.from_numpy(tile_cloud).to(dev), torch.from_numpy(row0).to(dev),
                    torch.from_numpy(lens).to(dev))
+
+    @classmethod
+    def from_host(cls, srcs: Sequence[torch.Tensor], tgts: Sequence[torch.Tensor], centers: Sequence[torch.Tensor],
+                  device: torch.device, extra: Optional[np.ndarray] = None, staging=None):
+        """Pack CPU clouds on the host and upload the batch with TWO asynchronous copies from pinned memory (floats:
+        packed xyz | centres | `extra`; int32: tile_cloud | cloud_row0 | cloud_len) on the current stream, instead of
+        one blocking copy per cloud.  Returns (batch, extra_on_device).  `staging` is an optional StagingBuffers that
+        recycles the pinned memory."""
+        B = len(srcs)
+        assert B == len(tgts) == len(centers) and B > 0
+        src_len = [int(t.shape[0]) for t in srcs]
+        tgt_len = [int(t.shape[0]) for t in tgts]
+        lens, row0, rows_src, rows_total, tile_cloud, max_chunks = cls.layout(src_len, tgt_len)
+        n_extra = 0 if extra is None else int(extra.size)
+        nf = rows_total * 3 + 2 * B * 3 + n_extra
+        ni = tile_cloud.size + 4 * B
+        fbuf, ibuf = (staging or StagingBuffers()).take(nf, ni)
+        f = fbuf.numpy()
+        f[: rows_total * 3] = 0.0
+        xyz_h = f[: rows_total * 3].reshape(rows_total, 3)
+        for i, t in enumerate(list(srcs) + list(tgts)):
+            xyz_h[int(row0[i]):int(row0[i]) + int(lens[i])] = t.reshape(-1, 3).numpy()
+        cen = f[rows_total * 3: rows_total * 3 + 6 * B].reshape(2 * B, 3)
+        cen[:] = 0.0
+        for i in range(B):
+            cen[i] = centers[i].reshape(3).numpy()
+        if n_extra:
+            f[rows_total * 3 + 6 * B: nf] = np.asarray(extra, dtype=np.float32).reshape(-1)
+        iv = ibuf.numpy()
+        iv[: tile_cloud.size] = tile_cloud
+        iv[tile_cloud.size: tile_cloud.size + 2 * B] = row0
+        iv[tile_cloud.size + 2 * B: ni] = lens
+        fd = fbuf[:nf].to(device, non_blocking=True)
+        idv = ibuf[:ni].to(device, non_blocking=True)
+        batch = cls(B, src_len, tgt_len, row0, lens, rows_src, rows_total, max_chunks, fd[: rows_total * 3].view(rows_total, 3),
+                    fd[rows_total * 3: rows_total * 3 + 6 * B].view(2 * B, 3), idv[: tile_cloud.size],
+                    idv[tile_cloud.size: tile_cloud.size + 2 * B], idv[tile_cloud.size + 2 * B: ni])
+        return batch, fd[rows_total * 3 + 6 * B: nf]
 
     # ---- views used by the search / solve stage ------------------------------------------------
     @property

@@ -198,7 +198,7 @@ def fake_items(net, items, ids, corr, dis_thresh, icp, device=None, pred_hook=No
     for k, i in enumerate(ids):
         rows[k] = [i, i %% 8, 1.0, float(i %% 3 != 0), 1.0 + i, 0.01 * i, 0.1, 0.5 * i]
     return rows
-ev.evaluate_items = fake_items
+ev.evaluate_items_async = lambda *a, **k: (lambda: fake_items(*a, **k))
 out = ev.evaluate_loader(None, DS(), batch_pairs=4, verbose=False)
 allrows = fake_items(None, None, list(range(n)), None, None, None)
 want = ev.aggregate_rows(allrows, "median")
