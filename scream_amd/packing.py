@@ -123,11 +123,11 @@ class PackedBatch:
         f[: rows_total * 3] = 0.0
         xyz_h = f[: rows_total * 3].reshape(rows_total, 3)
         for i, t in enumerate(list(srcs) + list(tgts)):
-            xyz_h[int(row0[i]):int(row0[i]) + int(lens[i])] = t.reshape(-1, 3).numpy()
+            xyz_h[int(row0[i]):int(row0[i]) + int(lens[i])] = t.detach().reshape(-1, 3).float().cpu().numpy()
         cen = f[rows_total * 3: rows_total * 3 + 6 * B].reshape(2 * B, 3)
         cen[:] = 0.0
         for i in range(B):
-            cen[i] = centers[i].reshape(3).numpy()
+            cen[i] = centers[i].detach().reshape(3).float().cpu().numpy()
         if n_extra:
             f[rows_total * 3 + 6 * B: nf] = np.asarray(extra, dtype=np.float32).reshape(-1)
         iv = ibuf.numpy()

@@ -284,3 +284,15 @@ def test_open_gf_voxel_down_sample_and_sample_layout():
     dsm, coarse, dem, c = SyntheticDEM(1, seed0=3, points=500)[0]
     assert dsm.dtype == torch.float32 and dsm.shape == dem.shape == (500, 3) and coarse.shape[1] == 3
     assert torch.equal(dsm[:, :2], dem[:, :2]) and (dsm[:, 2] >= dem[:, 2] - 1e-6).all()
+
+
+def test_staging_buffers_alternate_and_grow():
+    from scream_amd.packing import StagingBuffers
+    st = StagingBuffers()
+    f0, i0 = st.take(100, 10)
+    f1, i1 = st.take(50, 5)
+    assert f0.data_ptr() != f1.data_ptr() and f0.numel() >= 100 and i1.numel() >= 5
+    f2, _ = st.take(80, 8)
+    assert f2.data_ptr() == f0.data_ptr()      # slot 0 again, large enough: reused
+    f3, _ = st.take(5000, 8)
+    assert f3.numel() >= 5000                   # slot 1 regrown
