@@ -22,6 +22,8 @@ Extra objects on that line:
   variant_registered_pred -- the same step re-timed (outside the headline region) with src_pred replaced, after the
                   forward, by GT-registered src + 1 cm noise, so that the search/gather/Kabsch stages see realistic
                   correspondence counts (random weights leave almost none): pairs/s, mean K, fraction registered.
+  power        -- socket power and shader clock (rocm-smi) sampled by rank 0 beside those variant steps (>= 1 s): the
+                  split GEMM runs into the 1400 W cap, which is what bounds it.
   cpu_baseline -- the CPU oracle (oracle/scream_ref.py, a PyTorch-CPU restatement validated against the
                   reference) on a bounded sample of the same pairs, on this box's host cores.
 """
@@ -219,13 +221,43 @@ def main():
         elapsed = float(t.item())
 
     # ---- the same step with realistic correspondence counts (outside the headline's timed region) -------------
+    # rank 0 also samples the socket power and the shader clock beside it: the split GEMM runs at the 1400 W cap
     n_var = min(args.steps, 5)
+    power_samples, sampling = [], [rank == 0]
+
+    def sample_power():
+        import re
+        import subprocess
+        pat = re.compile(r"^card%d,.*\((\d+)Mhz\),\d,\(\d+Mhz\),\w,(\d+\.\d+)\s*$" % local)
+        while sampling[0]:
+            try:
+                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=5).stdout
+                for line in out.splitlines():
+                    m = pat.match(line.strip())
+                    if m:
+                        power_samples.append((int(m.group(1)), float(m.group(2))))
+            except Exception:
+                return
+            time.sleep(0.02)
+
+    import threading
+    sampler = threading.Thread(target=sample_power, daemon=True)
     fence()
+    sampler.start()
     t1 = time.perf_counter()
-    for _ in range(n_var):
+    n_run = 0
+    while n_run < n_var or (rank == 0 and world == 1 and time.perf_counter() - t1 < 1.0):  # >= 1 s so rocm-smi sees it
         re_v, te_v, k_v = step(None, registered=True)
+        n_run += 1
     fence()
     var_elapsed = time.perf_counter() - t1
+    sampling[0] = False
+    sampler.join(timeout=10)
+    n_var = n_run
+    steady = power_samples[len(power_samples) // 2:]  # the governor needs a few hundred ms to settle
+    power = ({"socket_power_w": round(sum(p for _, p in steady) / len(steady), 1),
+              "sclk_mhz": round(sum(c for c, _ in steady) / len(steady)), "samples": len(steady),
+              "source": "rocm-smi --showpower --showclocks, sampled beside the variant steps"} if steady else None)
     variant = {"value": round(B * world * n_var / var_elapsed, 3), "unit": "pairs/s", "steps": n_var,
                "what": "same step, src_pred replaced after the forward by GT-registered src + 1 cm noise (SURVEY.md 8d)",
                "mean_correspondences": round(float(k_v.float().mean().item()), 1),
@@ -312,6 +344,7 @@ def main():
                          "by_gemm_shape": by_gemm_shape},
         }
         out["variant_registered_pred"] = variant
+        out["power"] = power
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(items, sd, 16)
         print(json.dumps(out), flush=True)
