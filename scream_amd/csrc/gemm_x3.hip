@@ -23,8 +23,8 @@
 //     k-tile after next in flight; the barrier is followed directly by MFMAs (the first step's operand split was done
 //     at the end of the previous k-tile, the requests go out between the two steps).
 //   * The A loads are plain inline asm: hipcc's own vmcnt bookkeeping cannot count across the epilogue's stores and
-//     the loop back edge and would wait for vmcnt(0).  The first barrier of an output tile leaves the previous
-//     epilogue's stores in flight (vmcnt(4 + their number)).
+//     the loop back edge and would wait for vmcnt(0) everywhere.  Counted waits are used only where nothing but loads
+//     is in flight; the first barrier of an output tile, behind the previous epilogue's stores, drains the queue.
 //   * The two waves of a SIMD are not symmetric: the older one gets the matrix pipe first (s_memtime stamps,
 //     tools/x3_stamps.py: 1.8 k cycles for its first 48 MFMAs against 3.8 k for the younger wave's), so the younger
 //     waves (4-7) do their operand split AFTER the barrier, where they would be starved anyway, the older ones before.
@@ -163,7 +163,6 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
 
     bf16x8 pa_s0[3];  // split planes of the first 16-deep step of the k-tile about to be computed
     const bool late = wave >= 4;  // the second wave of each SIMD
-    int first_younger = 0;
 #ifdef X3_STAMPS
     int tile_no = 0;
 #endif
@@ -222,22 +221,17 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
                 split3(lo, hi, pa[0], pa[1], pa[2]);
             }
         };
-        // wait for everything but the n youngest vector-memory operations of this wave, then the workgroup barrier
-        auto first_barrier = [&]() {
-            if (first_younger == 32) ring_barrier<36>();
-            else if (first_younger == 16) ring_barrier<20>();
-            else ring_barrier<4>();
-        };
         auto step = [&](auto tail, auto first, int kt, int stage, f32x4 (&ac)[4], f32x4 (&an1)[4], f32x4 (&an2)[4]) {
             constexpr int TAIL = decltype(tail)::value;
             constexpr bool FIRST = decltype(first)::value;
             // Everything but the four youngest operations (A(kt+1)) has landed: W k-tile kt is in LDS for every wave
-            // and every wave is done reading the other stage.  On the first k-tile of an output tile the stores of the
-            // previous epilogue are younger still and are left in flight as well (first_younger of them at least).
+            // and every wave is done reading the other stage.  The first k-tile of an output tile drains everything:
+            // the previous epilogue's STORES are in the queue there, and a counted wait is only sound among loads --
+            // stores complete out of order with respect to older loads (tools/x3_soak.py caught vmcnt(4 + #stores)
+            // returning with a load still in flight, once in ~10^8 tile boundaries).
             STAMP(4 + kt * 4 + 0);
-            if (FIRST) first_barrier();
-            else if (TAIL <= 1) ring_barrier<4>();
-            else ring_barrier<0>();
+            if (FIRST || TAIL == 2) ring_barrier<0>();
+            else ring_barrier<4>();
             STAMP(4 + kt * 4 + 1);
             if (FIRST || late) {  // the younger waves of each SIMD split their first half here: they would only be
                 asm volatile("" : "+v"(ac[0]));  // starved by the older wave's MFMAs for that long anyway, and the
@@ -305,8 +299,6 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
             ga = a_ptr(m0, rows_ok);
         }
         if (has_next) request_first();
-        // vector-memory operations this wave is about to issue behind that request, at least (see first_barrier)
-        first_younger = (X3_ABLATE != 0 || !rows_cur) ? 0 : (EPI == SCREAM_EPI_QKV && n0_cur >= ep.n_act) ? 16 : 32;
         if (X3_ABLATE & 1) {
             float keep = 0.f;
 #pragma unroll
