@@ -466,3 +466,13 @@ def test_gemm_x3_persistent_blocks_many_tiles(epi):
         qb, pb = ops.gemm_qkv(A, W, 256, tile_cloud, crow0, clen, 0)
         torch.testing.assert_close(qa, qb, rtol=1e-5, atol=2e-5)
         torch.testing.assert_close(pa, pb, rtol=1e-4, atol=2e-3)  # sums of 128 products of O(1) terms
+
+
+def test_gemm_x3_two_stream_soak_short():
+    """Six seconds of tools/x3_soak.py: random shapes and epilogues of the x3 GEMM against the fp32-MFMA GEMM on two
+    HIP streams at once (the lanes configuration).  The long form of this test is what caught a counted wait that was
+    unsound across the epilogue's stores (once in ~10^5 launches); the short form guards against coarser mistakes."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "x3_soak.py"), "6", "3"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
