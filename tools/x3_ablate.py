@@ -16,7 +16,7 @@ def build():
     procs = []
     for bits, _ in VARIANTS:
         cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-DX3_ABLATE=%d" % bits, *EXTRA,
-               os.path.join(ROOT, "scream_amd/csrc/gemm_x3.hip"), "-o", os.path.join(OUT, "x3_%d.so" % bits)]
+               os.path.join(ROOT, os.environ.get("X3_SRC", "scream_amd/csrc/gemm_x3.hip")), "-o", os.path.join(OUT, "x3_%d.so" % bits)]
         procs.append(subprocess.Popen(cmd))
         if len(procs) == 4:
             for p in procs: assert p.wait() == 0
