@@ -296,3 +296,37 @@ def test_staging_buffers_alternate_and_grow():
     assert f2.data_ptr() == f0.data_ptr()      # slot 0 again, large enough: reused
     f3, _ = st.take(5000, 8)
     assert f3.numel() >= 5000                   # slot 1 regrown
+
+
+def test_x3_kernel_k_loop_has_no_register_spills(tmp_path):
+    """gemm_x3.hip loads its A operands with inline asm, so the compiler does not know those registers are in flight:
+    a spill (scratch store) of one of them inside the k-loop would save stale bytes.  Compile to assembly and require
+    the k-loop of every instantiation to be free of scratch traffic (spills outside it only touch loop invariants)."""
+    import re, shutil, subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scream_amd", "csrc", "gemm_x3.hip")
+    out = tmp_path / "x3.s"
+    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, capture_output=True, timeout=600)
+    lines = out.read_text().splitlines()
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN.*gemm_x3_kernelILi\d+E.*:", l)]
+    assert len(starts) == 6
+    checked = 0
+    for a, b in zip(starts, starts[1:] + [len(lines)]):
+        body = lines[a:b]
+        hdr = [i for i, l in enumerate(body) if "Inner Loop Header: Depth=2" in l]
+        assert hdr, "k-loop not found"
+        i = hdr[0]
+        labels = {l.split(":")[0]: k for k, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
+
+        def backward(k):  # a branch to a label at or above the loop header: the latch of the (rotated) k-loop
+            m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)\b", body[k])
+            return m is not None and labels.get(m.group(1), len(body)) <= i
+
+        j = next(k for k in range(i, len(body)) if backward(k))
+        loop = body[i:j]
+        assert sum("v_mfma_f32_32x32x16_bf16" in l for l in loop) == 288  # three k-tiles of 96 MFMAs
+        assert not any("scratch_" in l for l in loop), "register spill inside the x3 k-loop"
+        checked += 1
+    assert checked == 6
