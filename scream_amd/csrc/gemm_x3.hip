@@ -149,7 +149,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
         asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(a[2]) : "v"(p));
         asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(a[3]) : "v"(p));
     };
-    // issue order D(0), A(0), A(1): the first barrier's vmcnt(4) must leave exactly A(1) in flight
+    // first requests of an output tile, D(0), A(0), A(1) (its first barrier drains the queue; the order is kept pinned)
     auto request_first = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         dma_w(n0, 0, 0);
