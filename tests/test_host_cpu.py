@@ -328,5 +328,9 @@ def test_x3_kernel_k_loop_has_no_register_spills(tmp_path):
         loop = body[i:j]
         assert sum("v_mfma_f32_32x32x16_bf16" in l for l in loop) == 288  # three k-tiles of 96 MFMAs
         assert not any("scratch_" in l for l in loop), "register spill inside the x3 k-loop"
+        # the first operand registers of the NEXT tile are in flight during the epilogue as well: spill stores are only
+        # tolerated in the kernel prologue, where they save loop invariants
+        outer = next(k for k, l in enumerate(body) if "Loop Header: Depth=1" in l)
+        assert not any("scratch_store" in l for l in body[outer:]), "spill store inside the persistent tile loop"
         checked += 1
     assert checked == 6
