@@ -334,3 +334,18 @@ def test_x3_kernel_k_loop_has_no_register_spills(tmp_path):
         assert not any("scratch_store" in l for l in body[outer:]), "spill store inside the persistent tile loop"
         checked += 1
     assert checked == 6
+
+
+def test_empty_dataset_evaluates_to_zeros():
+    from scream_amd import dist as sdist
+    from scream_amd import evaluate as ev
+
+    class Empty:
+        def __len__(self):
+            return 0
+
+        def __getitem__(self, i):
+            raise IndexError(i)
+
+    assert ev.aggregate_rows(np.zeros((0, sdist.ROW_WIDTH)), "median") == (0.0, 0.0, 0.0, 0.0)
+    assert ev.evaluate_loader(None, Empty(), verbose=False) == (0.0, 0.0, 0.0, 0.0)
