@@ -476,3 +476,19 @@ def test_gemm_x3_two_stream_soak_short():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "x3_soak.py"), "6", "3"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("shift", [40, -40, 100, -100])
+def test_gemm_x3_is_exactly_scale_invariant_at_full_size(shift):
+    """The split GEMM has no range caveat: bf16 keeps fp32's exponent, the three planes of 2^k * x are 2^k times the
+    planes of x, products and fp32 accumulation scale with them -- so gemm(2^k A) == 2^k gemm(A) BIT FOR BIT (as long
+    as nothing leaves the normal fp32 range), here at the row count of the headline workload and |k| up to 100."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    M = 333184
+    A = torch.randn(M, 256, device=DEV, generator=g)
+    W = torch.randn(256, 256, device=DEV, generator=g) / 16
+    base = ops.gemm_x3(A, ops.split_planes(W))
+    half = shift // 2
+    scaled = ops.gemm_x3(A * (2.0 ** half), ops.split_planes(W * (2.0 ** (shift - half))))
+    assert torch.equal(scaled * (2.0 ** -half) * (2.0 ** -(shift - half)), base)
+    assert torch.isfinite(scaled).all()
