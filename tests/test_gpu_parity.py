@@ -492,3 +492,26 @@ def test_gemm_x3_is_exactly_scale_invariant_at_full_size(shift):
     scaled = ops.gemm_x3(A * (2.0 ** half), ops.split_planes(W * (2.0 ** (shift - half))))
     assert torch.equal(scaled * (2.0 ** -half) * (2.0 ** -(shift - half)), base)
     assert torch.isfinite(scaled).all()
+
+
+def test_nn_search_at_65536_points_finds_a_permuted_copy():
+    """BASELINE config 5 size (65 536 points per cloud): the target cloud is a seeded permutation of the query cloud
+    plus a far-away decoy half, so the exact nearest neighbour of query i is known without an N x M matrix: the index
+    where the permutation put point i -- for every one of the 65 536 queries, all within the threshold."""
+    g = torch.Generator().manual_seed(9)
+    n = 65536
+    cells = torch.stack(torch.meshgrid(*[torch.arange(41)] * 3, indexing="ij"), dim=-1).reshape(-1, 3)[torch.randperm(41 ** 3, generator=g)[:n]]
+    q = (cells.float() + 0.5 + (torch.rand(n, 3, generator=g) - 0.5) * 0.4) / 20.5 - 1  # jittered grid: neighbours >= 0.029 apart
+    perm = torch.randperm(n, generator=g)
+    decoy = torch.rand(n // 2, 3, generator=g) * 2 + 5.0
+    r = torch.cat([q[perm], decoy])[torch.randperm(n + n // 2, generator=g)]
+    # where did query i go?  (r is a shuffle of [q[perm] | decoy]; match by exact coordinates through a hash of the bits)
+    key = lambda t: (t.view(torch.int32).to(torch.int64) * torch.tensor([1, 1 << 21, 1 << 42])).sum(dim=1)
+    order = torch.argsort(key(r))
+    pos = order[torch.searchsorted(key(r)[order], key(q))]
+    assert torch.equal(r[pos], q)
+    i32 = lambda a: dev(torch.tensor(a, dtype=torch.int32))
+    idx, dmin, valid = ops.nn_search(dev(q), dev(r), i32([0]), i32([n]), i32([0]), i32([r.shape[0]]), dev(torch.tensor([0.37])),
+                                     n, r.shape[0], 1e-4)
+    assert torch.equal(idx.cpu().long(), pos)
+    assert valid.cpu().bool().all() and float(dmin.abs().max()) < 2e-5  # |a|^2 <= 22 in units of s: cancellation noise only
