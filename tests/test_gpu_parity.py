@@ -515,3 +515,22 @@ def test_nn_search_at_65536_points_finds_a_permuted_copy():
                                      n, r.shape[0], 1e-4)
     assert torch.equal(idx.cpu().long(), pos)
     assert valid.cpu().bool().all() and float(dmin.abs().max()) < 2e-5  # |a|^2 <= 22 in units of s: cancellation noise only
+
+
+def test_kabsch_round_trip_at_65536_correspondences():
+    """Encode -> decode at the largest size: B = R A + t for a batch of known rigid motions and 65 536 correspondences
+    each; the solve must give R | t back within the north-star tolerance (1e-4 Frobenius), and composing it with the
+    inverse motion must give the identity."""
+    g = torch.Generator().manual_seed(21)
+    bs, K = 4, 65536
+    A = torch.rand(bs, K, 3, generator=g) * 2 - 1
+    Q, _ = torch.linalg.qr(torch.randn(bs, 3, 3, generator=g))
+    R = Q * torch.sign(torch.linalg.det(Q)).view(bs, 1, 1)   # proper rotations
+    t = torch.randn(bs, 3, 1, generator=g)
+    B = (R @ A.transpose(1, 2) + t).transpose(1, 2).contiguous()
+    T = ops.rigid_transform_3d_dense(dev(A), dev(B), None, 0.0).cpu()
+    want = torch.eye(4).repeat(bs, 1, 1)
+    want[:, :3, :3], want[:, :3, 3:] = R, t
+    assert float((T - want).flatten(1).norm(dim=1).max()) < 1e-4
+    back = torch.linalg.inv(want.double()) @ T.double()
+    assert float((back - torch.eye(4, dtype=torch.float64)).flatten(1).norm(dim=1).max()) < 1e-4
