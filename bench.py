@@ -173,7 +173,7 @@ def main():
                     rng.normal(scale=0.01 * it[4], size=it[0].shape).astype(np.float32))
             self.reg_pred = reg.to(dev)
 
-    lane_parts = [Lane([items[i] for i in rg]) for rg in lanes.split(B, args.lanes)]
+    lane_parts = [Lane([items[i] for i in rg]) for rg in lanes.split_weighted([it[0].shape[0] + it[1].shape[0] for it in items], args.lanes)]
     src_len = [n for ln in lane_parts for n in ln.batch.src_len]
     tgt_len = [n for ln in lane_parts for n in ln.batch.tgt_len]
     rows_total = sum(ln.batch.rows_total for ln in lane_parts)

@@ -153,7 +153,7 @@ def register_items_async(net, its: Sequence[tuple], centers: Sequence[torch.Tens
     device = device or next(net.parameters()).device
     if lanes is None:
         lanes = _lanes.DEFAULT_LANES if len(its) >= 8 else 1
-    parts = _lanes.split(len(its), lanes)
+    parts = _lanes.split_weighted([it[0].shape[0] + it[1].shape[0] for it in its], lanes)
     outs = _lanes.run(device, parts, lambda rg: _register_lane(
         net, [its[i] for i in rg], [centers[i] for i in rg], [pair_ids[i] for i in rg], corr, dis_thresh, icp, icp_dist,
         icp_iters, device, pred_hook))

@@ -36,6 +36,30 @@ def split(n_items: int, lanes: int) -> List[range]:
     return out
 
 
+def split_weighted(weights: Sequence[float], lanes: int) -> List[range]:
+    """Contiguous index ranges (never empty) with near-equal total weight: lane l ends where the running sum is closest
+    to (l + 1) / lanes of the total.  A lane's time follows its point count, so real batches (3DMatch clouds range
+    from 2 k to 10 k points) are split by weight = N_i + M_i rather than by pair count."""
+    n = len(weights)
+    lanes = max(1, min(lanes, n))
+    total = float(sum(weights))
+    if lanes == 1 or total <= 0:
+        return split(n, lanes)
+    prefix, acc = [], 0.0
+    for w in weights:
+        acc += float(w)
+        prefix.append(acc)
+    cuts, lo = [], 0
+    for l in range(1, lanes):
+        target = total * l / lanes
+        # candidates lo+1 .. n-(lanes-l): keep at least one item for this lane and for every lane after it
+        best = min(range(lo + 1, n - (lanes - l) + 1), key=lambda j: abs(prefix[j - 1] - target))
+        cuts.append(best)
+        lo = best
+    bounds = [0] + cuts + [n]
+    return [range(a, b) for a, b in zip(bounds, bounds[1:])]
+
+
 def run(device: torch.device, parts: Sequence, fn: Callable[[object], T]) -> List[T]:
     """fn(part) for every part, part i on lane stream i, forked from and joined to the current stream.  Tensors that
     fn allocates belong to the lane stream's pool; the join makes them safe to read on the current stream, and callers

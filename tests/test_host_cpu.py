@@ -258,6 +258,20 @@ def test_normalize_pair_matches_oracle_both_modes():
     assert len(item) == 9 and item[5].tolist() == [0, 2] and item[8] == 11 % 8
 
 
+def test_weighted_lane_split_balances_point_counts():
+    from scream_amd.lanes import split_weighted
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 9, 32):
+        w = rng.integers(2000, 20000, size=n).tolist()
+        for lanes in (1, 2, 3, 40):
+            parts = split_weighted(w, lanes)
+            assert len(parts) == min(lanes, n) and all(len(p) > 0 for p in parts)
+            assert [i for p in parts for i in p] == list(range(n))
+    w = [10000, 5000, 1000, 1000, 1000, 1000, 1000]  # half the weight sits in the first item
+    assert [list(p) for p in split_weighted(w, 2)] == [[0], [1, 2, 3, 4, 5, 6]]
+    assert [list(p) for p in split_weighted([5] * 8, 2)] == [[0, 1, 2, 3], [4, 5, 6, 7]]
+
+
 def test_lane_split_is_a_contiguous_partition():
     from scream_amd.lanes import split
     for n in (1, 2, 7, 8, 32, 33):
