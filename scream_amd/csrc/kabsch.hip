@@ -510,10 +510,10 @@ extern "C" int scream_icp_p2p(const float* src, const float* ref, const int32_t*
                                                                fitness_rmse, iters);
         SCREAM_LAUNCH_CHECK();
         // Long schedules (KITTI asks for up to 1000 iterations, evaluate_kitti.py:69) usually converge in tens:
-        // look at the flags every 8 iterations and stop launching once every pair is done.  Short schedules (the
+        // look at the flags every 32 iterations and stop launching once every pair is done.  Short schedules (the
         // 30-iteration default) never synchronise: converged pairs have frozen on the device and cost no search work,
         // and a host that does not block here can keep the other lane and the next batch queued.
-        if (max_iter > 64 && (it & 7) == 7 && it < max_iter) {
+        if (max_iter > 64 && (it & 31) == 31 && it < max_iter) {
             host_state.resize(n_pairs);
             e = hipMemcpyAsync(host_state.data(), state, sizeof(IcpState) * n_pairs, hipMemcpyDeviceToHost, st);
             if (e != hipSuccess) return (int)e;
