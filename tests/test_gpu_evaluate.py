@@ -228,3 +228,42 @@ def test_open_gf_dem_evaluation_vs_oracle():
     np.testing.assert_allclose(rows, want, rtol=2e-4, atol=1e-4)
     out = evaluate_dem_generation(net, ds, batch_samples=2, verbose=False)
     np.testing.assert_allclose(out, rows.mean(axis=0), rtol=1e-9)
+
+
+def test_callable_icp_accept_only_if_better():
+    """evaluate_3d_match.py:106-119 with a user-supplied refinement (the slot of o3d.registration_icp): a refinement that
+    returns the ground-truth pose is accepted (RE, TE -> ~0), one that returns a worse pose is rejected and the Kabsch
+    result stays."""
+    from scream_amd.evaluate import evaluate_items, gt_pose_metric
+    from scream_amd.model import PointTransformer
+    net = PointTransformer(256, 1, 1)
+    net.load_state_dict(make_state_dict(2, 256, 1, 1))
+    net = net.to(DEV).eval()
+    ds = SyntheticPairs("3dmatch", 3, seed0=90)
+    items = [ds[i] for i in range(3)]
+
+    def hook(batch, src_pred, ids):
+        out = src_pred.clone()
+        for k, i in enumerate(ids):
+            r0 = int(batch.cloud_row0_host[k])
+            out[r0:r0 + items[i][0].shape[0]] = _noisy_registered(items[i], i).to(DEV)
+        return out
+
+    base = evaluate_items(net, items, [0, 1, 2], "tgt", 0.1, None, pred_hook=hook)
+    calls = []
+
+    def perfect(it, T_init):
+        calls.append(T_init.shape)
+        return gt_pose_metric(it[2], it[3], it[4], it[5]).numpy()
+
+    def worse(it, T_init):
+        T = np.array(T_init, dtype=np.float32)
+        T[:3, 3] += 5.0
+        return T
+
+    good = evaluate_items(net, items, [0, 1, 2], "tgt", 0.1, perfect, pred_hook=hook)
+    bad = evaluate_items(net, items, [0, 1, 2], "tgt", 0.1, worse, pred_hook=hook)
+    assert calls == [(4, 4)] * 3
+    assert (good[:, sdist.COL_TE] < 1e-5).all() and (good[:, sdist.COL_RE] < 0.05).all()
+    assert (good[:, sdist.COL_TE] <= base[:, sdist.COL_TE]).all()
+    np.testing.assert_array_equal(bad, base)
