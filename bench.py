@@ -2,7 +2,11 @@
 """Headline benchmark: registration pairs/sec on synthetic 3DMatch_test-like clouds (BASELINE.json
 configs[1]: voxel 0.0625 m, ~5k points per cloud, batch-of-pairs = 32 per GPU).
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU over RCCL.  Started under torch.distributed.run (RANK / WORLD_SIZE in the environment)
+this process IS a rank; started bare, it stays a CPU-only parent that spawns the N ranks as child processes before
+anything touches a GPU (launch_ranks), forwards rank 0's JSON line and exits non-zero if any rank failed.
 
 One *step* = the hot path A1-A10 over one batch of 32 pairs per GPU, inputs resident
 in HBM: PointTransformer forward -> thresholded 1-NN -> fused gather + Kabsch -> RE/TE (+ the all-gather
@@ -103,6 +107,74 @@ def cpu_baseline(items, sd, max_pairs, budget_s=25.0):
                       % (done, len(items), cores, t_total)}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def rank_env(base_env, rank, world, port):
+    """Environment of child rank `rank` (torchrun's contract: one process per GPU, LOCAL_RANK = device index)."""
+    env = dict(base_env)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    return env
+
+
+def launch_ranks(world, argv, timeout_s=None):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks as CHILDREN of this (GPU-free) process.
+    Rank 0's stdout (the one JSON line) is forwarded; every rank's stderr goes to ours.  Returns the exit code:
+    0 only if every rank exited 0.  A failing rank takes the others down (they would hang in the next collective)."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                      env=rank_env(os.environ, r, world, port),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    t_end = None if timeout_s is None else time.monotonic() + timeout_s
+    rc, out0 = 0, b""
+    try:
+        pending = set(range(world))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print("bench.py: rank %d exited with %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()
+            if pending:
+                if 0 in pending:  # keep rank 0's pipe drained
+                    try:
+                        out0 += procs[0].communicate(timeout=0.2)[0] or b""
+                    except subprocess.TimeoutExpired:
+                        pass
+                else:
+                    time.sleep(0.2)
+                if t_end is not None and time.monotonic() > t_end:
+                    print("bench.py: ranks still running after %.0f s; stopping them" % timeout_s, file=sys.stderr)
+                    rc = rc or 124
+                    for q in pending:
+                        procs[q].terminate()
+                    t_end = None
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    if procs[0].stdout is not None and not procs[0].stdout.closed:
+        out0 += procs[0].stdout.read() or b""
+    # stdout carries the ONE JSON line; anything else a library printed there (gloo's connection banner) goes to stderr
+    for line in out0.decode(errors="replace").splitlines():
+        print(line, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,14 +186,33 @@ def main():
     ap.add_argument("--gen-procs", type=int, default=0, help="worker processes for synthetic data (0 = auto)")
     ap.add_argument("--workload", default="3dmatch", choices=["3dmatch", "kitti", "uniform64k"],
                     help="3dmatch = BASELINE configs[1] (the headline, default); kitti / uniform64k = configs[3] / [4] stress runs")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher rehearsal without a GPU: every rank joins a gloo group, all-gathers its rank and rank 0 prints them")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:  # bare `python bench.py --gpus N`: be the launcher
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+
+    if args.dry_run:  # exercises launch_ranks + the rendezvous only (tests/test_host_cpu.py); no GPU, no kernels
+        import torch
+        import torch.distributed as tdist
+        from scream_amd import dist as sdist
+        if os.environ.get("SCREAM_BENCH_DRY_FAIL_RANK") == str(rank):
+            raise SystemExit(3)
+        sdist.init_from_env("gloo")
+        seen = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        if world > 1:
+            tdist.all_gather(seen, torch.tensor([rank], dtype=torch.int64))
+            tdist.barrier()
+            tdist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": [int(t.item()) for t in seen],
+                              "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "steps": args.steps}), flush=True)
+        return
 
     global WORKLOAD
     WORKLOAD = args.workload
@@ -330,6 +421,7 @@ def main():
                                      "Kabsch, RE/TE), random-init weights seed 0" % (B, dis_thresh),
                        "pairs_per_step_per_gpu": B, "lanes": len(lane_parts), "mean_src_points": round(float(np.mean(src_len)), 1),
                        "mean_tgt_points": round(float(np.mean(tgt_len)), 1), "parallelism": "dp%d (pairs sharded, metric-row all-gather)" % world,
+                       "rccl_ranks": tdist.get_world_size() if world > 1 else 1, "collective_backend": backend if world > 1 else None,
                        "gemm_backend": net.gemm_backend},
             "roofline": {"bound": "mfma", "kernel": kernel_desc,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",

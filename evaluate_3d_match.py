@@ -1,7 +1,11 @@
 """Drop-in for the reference's ``evaluate_3d_match.py`` entry points (lines 31-50, 53-183).
 
     python evaluate_3d_match.py [--split 3DMatch_test|3DLoMatch_test|3DZeroMatch_test] [--params params/point-generator.pth]
-                                [--synthetic N] [--batch-pairs 32]
+                                [--synthetic N] [--batch-pairs 32] [--no-icp]
+
+Like the reference (evaluate_3d_match.py:106-119) every pose is refined by point-to-point ICP (here on the GPU:
+scream_icp_p2p, 0.1 m, 30 iterations) and the refinement is kept only where it improves both RE and TE; RR / RRE / RTE
+are those of the refined pose.  ``--no-icp`` (``icp=None`` in the Python API) reports the pre-ICP pose instead.
 
 With the reference's on-disk splits present (``<split>/src%d.npy`` ..., process_3d_match.py:38-40) it evaluates them;
 ``--synthetic N`` evaluates N seeded synthetic pairs instead (no dataset ships with either repository).
@@ -55,6 +59,7 @@ if __name__ == "__main__":
     ap.add_argument("--synthetic", type=int, default=0)
     ap.add_argument("--batch-pairs", type=int, default=32)
     ap.add_argument("--dis-thresh", type=float, default=0.1)
+    ap.add_argument("--no-icp", action="store_true", help="skip the ICP refinement of evaluate_3d_match.py:106-119")
     args = ap.parse_args()
     rank, world, local = _dist.init_from_env()
     device = torch.device("cuda", local)
@@ -67,4 +72,4 @@ if __name__ == "__main__":
     net.eval()
     ds = _dataset(args.split, args.synthetic)
     fn = {"3DMatch_test": evaluate_3d_match, "3DLoMatch_test": evaluate_3d_lo_match, "3DZeroMatch_test": evaluate_3d_zero_match}[args.split]
-    fn(net, args.dis_thresh, ds, batch_pairs=args.batch_pairs)
+    fn(net, args.dis_thresh, ds, batch_pairs=args.batch_pairs, icp=None if args.no_icp else "gpu")

@@ -80,8 +80,9 @@ int scream_kv_finalize(const float* kv_partial, const int32_t* cloud_row0, const
  * The weight matrix is pre-split and re-tiled ONCE by scream_pack_w_x3 (device to device): W [N,K] fp32 ->
  * W_packed, 6*N*K bytes: [3 planes][K/32 k-tiles][N][32] bf16 with plane p0 = bf16(W), p1 = bf16(W - p0),
  * p2 = bf16(W - p0 - p1), stored k-tile by k-tile in the order the kernel stages it in LDS.  A, C, residual and
- * bias stay fp32.  M % 128 == 0, N % 256 == 0, K = 64 + 96 j (64, 160, 256, ..., 1024: the k-loop rotates three
- * operand register sets).  A row-block [n0, n0 + n) of W must be packed on its
+ * bias stay fp32.  M % 128 == 0, N % 256 == 0, K = 64 + 192 j (64, 256, 448, ..., 1024: the k-loop rotates three
+ * operand register sets over two LDS stages, so the k-tile count K/32 is even and 2 mod 3; anything else is
+ * SCREAM_EUNSUPPORTED).  A row-block [n0, n0 + n) of W must be packed on its
  * own to be used as a GEMM operand on its own. */
 int scream_pack_w_x3(const float* W, int32_t N, int32_t K, void* W_packed, void* stream);
 int scream_gemm_x3_f32(const float* A, int64_t lda, const void* W_packed, float* C, int64_t ldc, int64_t M,

@@ -365,7 +365,7 @@ extern "C" int scream_gemm_x3_f32(const float* A, int64_t lda, const void* W_pla
                                   const float* residual, int64_t ldr, const float* gamma, const float* beta,
                                   void* stream) {
     SCREAM_REQUIRE(A && W_planes && C, SCREAM_EINVAL);
-    SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K >= 64 && K % 32 == 0 && (K / 32 - 2) % 3 == 0, SCREAM_EUNSUPPORTED);  // K = 64 + 96 j
+    SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K >= 64 && K % 64 == 0 && (K / 32 - 2) % 3 == 0, SCREAM_EUNSUPPORTED);  // K = 64 + 192 j: an EVEN number of k-tiles (stage = kt & 1), in groups of three after the first two
     SCREAM_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0 && ldc % 4 == 0, SCREAM_EINVAL);
     SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W_planes) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(C) & 15) == 0, SCREAM_EINVAL);
@@ -397,7 +397,7 @@ extern "C" int scream_gemm_qkv_x3_f32(const float* A, int64_t lda, const void* W
                                       const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
                                       float* kv_partial, void* stream) {
     SCREAM_REQUIRE(A && W_planes && kv_partial && tile_cloud && cloud_row0 && cloud_len, SCREAM_EINVAL);
-    SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K >= 64 && K % 32 == 0 && (K / 32 - 2) % 3 == 0, SCREAM_EUNSUPPORTED);  // K = 64 + 96 j
+    SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K >= 64 && K % 64 == 0 && (K / 32 - 2) % 3 == 0, SCREAM_EUNSUPPORTED);  // K = 64 + 192 j: an EVEN number of k-tiles (stage = kt & 1), in groups of three after the first two
     SCREAM_REQUIRE((n_q == 0 || n_q == XBN) && N == n_q + 2 * XBN && row_base >= 0 && row_base % SCREAM_ROW_TILE == 0,
                    SCREAM_EUNSUPPORTED);
     SCREAM_REQUIRE(n_q == 0 || (Q && ldq >= n_q && ldq % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0), SCREAM_EINVAL);

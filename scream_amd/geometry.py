@@ -51,19 +51,20 @@ def chamfer_distance(f: torch.Tensor, f_: torch.Tensor) -> torch.Tensor:
 
 
 def integrate_trans(R, t):
-    """utils.py:112-135."""
-    if len(R.shape) == 3:
-        if isinstance(R, torch.Tensor):
-            trans = torch.eye(4)[None].repeat(R.shape[0], 1, 1).to(R.device)
-        else:
-            trans = np.eye(4)[None]
-        trans[:, :3, :3] = R
-        trans[:, :3, 3:4] = t.view([-1, 3, 1])
+    """utils.py:112-135: [R | t; 0 0 0 1] for one pose ([3,3], [3,1]) or a batch ([bs,3,3], [bs,3,1]); torch tensors
+    give a float32 tensor on R's device (the reference fills a torch.eye), numpy arrays a float64 array."""
+    is_torch = isinstance(R, torch.Tensor)
+    batch_shape = tuple(R.shape[:-2])
+    if is_torch:
+        out = torch.zeros(batch_shape + (4, 4), dtype=torch.float32, device=R.device)
+        t = t.reshape(batch_shape + (3,)).to(out.dtype)
     else:
-        trans = torch.eye(4).to(R.device) if isinstance(R, torch.Tensor) else np.eye(4)
-        trans[:3, :3] = R
-        trans[:3, 3:4] = t
-    return trans
+        out = np.zeros(batch_shape + (4, 4))
+        t = np.asarray(t).reshape(batch_shape + (3,))
+    out[..., :3, :3] = R
+    out[..., :3, 3] = t
+    out[..., 3, 3] = 1.0
+    return out
 
 
 def rigid_transform_3d(A: torch.Tensor, B: torch.Tensor, weights: Optional[torch.Tensor] = None,

@@ -153,6 +153,11 @@ class PointTransformer(nn.Module):
         mt.c4_w, mt.c4_b = dev_f32(self.coor_mlp[4].weight[:, :, 0]), dev_f32(self.coor_mlp[4].bias)
         self._packed = (mt, (layers, tgt_layers), keep)
         self._packed_sig = sig
+        # the pack kernels and copies above were enqueued on the CURRENT stream; any other stream (a concurrent lane,
+        # scream_amd/lanes.py) must order its first use of these buffers behind them (forward_packed waits once per stream)
+        self._packed_event = torch.cuda.Event()
+        self._packed_event.record(torch.cuda.current_stream(dev))
+        self._packed_streams = {torch.cuda.current_stream(dev).cuda_stream}
         return self._packed
 
     # ------------------------------------------------------------------ batched entry
@@ -161,6 +166,9 @@ class PointTransformer(nn.Module):
         mt, _layers, _keep = self._pack_weights()
         lib = _lib.load()
         dev = batch.xyz.device
+        if ops._stream() not in self._packed_streams:  # first forward of this stream since the weights were packed
+            torch.cuda.current_stream(dev).wait_event(self._packed_event)
+            self._packed_streams.add(ops._stream())
         need = lib.scream_forward_workspace_bytes(batch.rows_src, batch.rows_total, batch.n_pairs, batch.max_chunks)
         # one scratch buffer per stream: concurrent lanes (scream_amd/lanes.py) run forwards of the same model side by side
         if self._ws is None:

@@ -60,7 +60,7 @@ def test_evaluate_loader_rows_vs_oracle(kind, corr, method):
     np.testing.assert_allclose(rows[:, sdist.COL_LOSS], want[:, sdist.COL_LOSS], rtol=1e-5)
     if corr == "tgt":
         assert rows[:, sdist.COL_SUCCESS].sum() >= 4  # a near-GT prediction registers
-    out = evaluate_loader(net, ds, corr=corr, dis_thresh=0.1, re_static_method=method, batch_pairs=2, verbose=False, pred_hook=hook)
+    out = evaluate_loader(net, ds, corr=corr, dis_thresh=0.1, re_static_method=method, batch_pairs=2, verbose=False, pred_hook=hook, icp=None)
     np.testing.assert_allclose(out, aggregate_rows(rows, method), rtol=1e-6, atol=1e-9)  # batching does not change results
 
 

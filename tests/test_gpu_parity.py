@@ -90,9 +90,12 @@ def test_gemm_x3_rejects_unsupported_k():
     A = torch.zeros(128, 128, device=DEV)
     with pytest.raises(ScreamHipError):
         ops.split_planes(torch.zeros(256, 48, device=DEV))  # K % 32
-    Wp = torch.zeros(3, 4, 256, 32, device=DEV, dtype=torch.bfloat16)  # K = 128 is not 64 + 96 j
+    Wp = torch.zeros(3, 4, 256, 32, device=DEV, dtype=torch.bfloat16)  # K = 128 is not 64 + 192 j
     with pytest.raises(ScreamHipError):
         ops.gemm_x3(A, Wp)
+    # K = 160: five k-tiles. 2 mod 3 but ODD -- the two-stage ring would read a stale stage (round-1 advisor finding)
+    with pytest.raises(ScreamHipError):
+        ops.gemm_x3(torch.zeros(128, 160, device=DEV), torch.zeros(3, 5, 256, 32, device=DEV, dtype=torch.bfloat16))
 
 
 @pytest.mark.parametrize("kind", ["f32", "x3"])
