@@ -236,10 +236,93 @@ def main():
         for p in range(3):
             infos.append(np.array([lines[p * 7 + j].split() for j in range(1, 7)], dtype=np.float32))
     np.savez(os.path.join(OUT, "info.npz"), info=np.stack(infos))
+    dataset_items(rng)
     print("golden fixtures written to", OUT)
     for fn in sorted(os.listdir(OUT)):
         print("  %-20s %8d B" % (fn, os.path.getsize(os.path.join(OUT, fn))))
 
 
+def dataset_items(rng):
+    """A12: the reference's OWN test-set items.  ThreeDMatchTest / ThreeDLoMatchTest / ThreeDZeroMatchTest
+    (datasets/three_d_match.py:219-294) and KITTI_Test (datasets/kitti.py:328-350, norm_pc :268-273) read
+    '<split>/src%d.npy' ... relative to the working directory, so small seeded pairs are written in that on-disk layout
+    (process_3d_match.py:38-40,199-200; process_kitti.py:72-74) into a temporary directory, the reference classes are
+    run there, and raw inputs + the 9-/6-tuples they return are stored.  Poses and 6x6 information matrices are real
+    benchmark metadata (datasets/3DMatch/indoor/*.pkl, info/**/gt.info: data files)."""
+    import tempfile
+    for name in ("cv2", "open3d", "igraph"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.path.insert(0, REF)
+    import datasets.kitti as ref_kitti
+    import datasets.three_d_match as ref_3dm
+    sys.path.remove(REF)
+    with open(os.path.join(REF, "datasets/3DMatch/indoor/3DMatch.pkl"), "rb") as f:
+        meta = pickle.load(f)
+    scenes = sorted(ref_3dm.scene_name_to_idx)
+    infos = np.load(os.path.join(OUT, "info.npz"))["info"]
+    rec = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            k = 0
+            for split, cls in (("3DMatch_test", ref_3dm.ThreeDMatchTest), ("3DLoMatch_test", ref_3dm.ThreeDLoMatchTest),
+                               ("3DZeroMatch_test", ref_3dm.ThreeDZeroMatchTest)):
+                os.makedirs(os.path.join(split, "info"))
+                names = []
+                for i in range(3):
+                    n, m = int(rng.integers(150, 400)), int(rng.integers(150, 400))
+                    T = np.eye(4)
+                    T[:3, :3], T[:3, 3:] = meta["rot"][37 * k + 5], meta["trans"][37 * k + 5]
+                    tgt = rng.uniform(-1.5, 2.5, size=(m, 3))
+                    src = (rng.uniform(-1.5, 2.5, size=(n, 3)) - T[:3, 3]) @ T[:3, :3]  # R src + t lies in the same box
+                    idx = np.array([int(rng.integers(0, 30)), int(rng.integers(0, 30))], dtype=np.int64)
+                    cov = infos[k % len(infos)]
+                    np.save("%s/src%d.npy" % (split, i), src)
+                    np.save("%s/tgt%d.npy" % (split, i), tgt)
+                    np.save("%s/T%d.npy" % (split, i), T)
+                    np.save("%s/info/idx%d.npy" % (split, i), idx)
+                    np.save("%s/info/covariance%d.npy" % (split, i), cov)
+                    names.append(scenes[(3 * k + 1) % 8])
+                    pre = "%s_%d_" % (split, i)
+                    rec.update({pre + "src": src, pre + "tgt": tgt, pre + "T": T, pre + "idx": idx, pre + "cov": cov,
+                                pre + "scene_name": np.array(names[-1])})
+                    k += 1
+                with open(os.path.join(split, "info", "scene_names.txt"), "w") as f:
+                    f.writelines(nm + "\n" for nm in names)
+                ds = cls()
+                for i in range(3):
+                    item = ds[i]
+                    pre = "%s_%d_out_" % (split, i)
+                    for key, val in zip(("src", "tgt", "rot", "trans", "s", "idx", "cov", "c", "scene"), item):
+                        rec[pre + key] = val.numpy() if torch.is_tensor(val) else np.asarray(val)
+            os.makedirs("KITTI_test")
+            for i in range(3):
+                n, m = int(rng.integers(200, 500)), int(rng.integers(200, 500))
+                yaw = float(rng.uniform(-0.2, 0.2))
+                T = np.eye(4)
+                T[:3, :3] = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1.0]])
+                T[:3, 3] = [rng.uniform(-10, 10), rng.uniform(-10, 10), rng.uniform(-0.5, 0.5)]
+                box = np.array([60.0, 45.0, 4.0])
+                tgt = rng.uniform(-1, 1, size=(m, 3)) * box
+                src = (rng.uniform(-1, 1, size=(n, 3)) * box - T[:3, 3]) @ T[:3, :3]
+                np.save("KITTI_test/src%d.npy" % i, src)
+                np.save("KITTI_test/tgt%d.npy" % i, tgt)
+                np.save("KITTI_test/T%d.npy" % i, T)
+                pre = "KITTI_test_%d_" % i
+                rec.update({pre + "src": src, pre + "tgt": tgt, pre + "T": T})
+                item = ref_kitti.KITTI_Test()[i]
+                for key, val in zip(("src", "tgt", "rot", "trans", "s", "c"), item):
+                    rec[pre + "out_" + key] = val.numpy() if torch.is_tensor(val) else np.asarray(val)
+                c_ref, s_ref = ref_kitti.norm_pc(np.concatenate([(T[:3, :3] @ src.T + T[:3, 3:]).T, tgt], axis=0))
+                rec[pre + "norm_pc_c"], rec[pre + "norm_pc_s"] = np.asarray(c_ref), np.asarray(s_ref)
+        finally:
+            os.chdir(cwd)
+    np.savez(os.path.join(OUT, "dataset_items.npz"), **rec)
+
+
 if __name__ == "__main__":
-    main()
+    if "--dataset-items-only" in sys.argv:  # adds tests/golden/dataset_items.npz without regenerating the other fixtures
+        dataset_items(np.random.default_rng(20261004))
+    else:
+        main()

@@ -21,7 +21,8 @@ def _noisy_registered(item, pair_id):
     return (rot @ src.T + trans).T + torch.from_numpy(rng.normal(scale=0.01 * s, size=src.shape).astype(np.float32))
 
 
-@pytest.mark.parametrize("kind,corr,method", [("3dmatch", "tgt", "median"), ("zero", "src_pred", "mean")])
+# the three splits of evaluate_3d_match.py:174-183 (BASELINE configs[1] and both halves of configs[2])
+@pytest.mark.parametrize("kind,corr,method", [("3dmatch", "tgt", "median"), ("lo", "tgt", "median"), ("zero", "src_pred", "mean")])
 def test_evaluate_loader_rows_vs_oracle(kind, corr, method):
     from scream_amd.evaluate import aggregate_rows, evaluate_items, evaluate_loader
     from scream_amd.model import PointTransformer
@@ -59,7 +60,7 @@ def test_evaluate_loader_rows_vs_oracle(kind, corr, method):
     np.testing.assert_allclose(rows[:, sdist.COL_RMSE], want[:, sdist.COL_RMSE], atol=2e-4)
     np.testing.assert_allclose(rows[:, sdist.COL_LOSS], want[:, sdist.COL_LOSS], rtol=1e-5)
     if corr == "tgt":
-        assert rows[:, sdist.COL_SUCCESS].sum() >= 4  # a near-GT prediction registers
+        assert rows[:, sdist.COL_SUCCESS].sum() >= 4  # a near-GT prediction registers (low overlap included)
     out = evaluate_loader(net, ds, corr=corr, dis_thresh=0.1, re_static_method=method, batch_pairs=2, verbose=False, pred_hook=hook, icp=None)
     np.testing.assert_allclose(out, aggregate_rows(rows, method), rtol=1e-6, atol=1e-9)  # batching does not change results
 
@@ -123,6 +124,43 @@ def test_gpu_icp_vs_oracle_loop():
         assert abs(fr[i, 0] - fit) < 5e-3 and abs(fr[i, 1] - rmse) < 1e-3
         assert np.linalg.norm(T[i] - Tgt) < 0.5 * np.linalg.norm(T0[i] - Tgt)
         assert 1 <= iters[i] <= 30 and abs(int(iters[i]) - n_it) <= 3
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5])
+def test_gpu_icp_matches_oracle_iteration_by_iteration(k):
+    """The same loop, compared where it is well defined: after exactly k updates (convergence test disabled) from the
+    same start, device and oracle have used the same correspondences and agree to 1e-4 Frobenius -- a per-iteration
+    statement instead of 'both end near the same fixed point'.  (Parity with open3d itself stays UNPINNED: open3d is
+    not in the image; oracle/icp_ref.py restates its published RegistrationICP loop.)"""
+    from oracle.icp_ref import icp_p2p as icp_ref
+    from scream_amd import ops
+    from scream_amd.packing import PackedBatch
+    items = [SyntheticPairs(kind, 1, seed0=70 + j)[0] for j, kind in enumerate(("3dmatch", "lo"))]
+    batch = PackedBatch.from_pairs([it[0].to(DEV) for it in items], [it[1].to(DEV) for it in items], None)
+    s = torch.tensor([it[4] for it in items], dtype=torch.float32, device=DEV)
+    c = torch.stack([it[7] for it in items]).to(DEV)
+    rng = np.random.default_rng(k)
+    T0 = []
+    for it in items:
+        Tgt = O.gt_pose_metric(it[2], it[3], it[4], it[7]).double().numpy()
+        ang = np.radians(1.5)
+        P = np.eye(4)
+        P[:3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+        P[:3, 3] = rng.normal(scale=0.015, size=3)
+        T0.append((P @ Tgt).astype(np.float32).astype(np.float64))  # the device starts from the fp32 pose: so does the oracle
+    T0 = np.stack(T0)
+    tgt_row0 = (batch.tgt_row0 - batch.rows_src).contiguous()
+    T, fr, iters = ops.icp_p2p(batch.xyz[: batch.rows_src], batch.xyz[batch.rows_src:], batch.src_row0, batch.src_len_dev,
+                               tgt_row0, batch.tgt_len_dev, s, c, torch.from_numpy(T0).float().to(DEV),
+                               max(batch.src_len), max(batch.tgt_len), 0.1, k, 0.0, 0.0)
+    T, fr, iters = T.cpu().numpy().astype(np.float64), fr.cpu().numpy(), iters.cpu().numpy()
+    for i, it in enumerate(items):
+        src_m = (it[0] / it[4] + it[7]).double().numpy()  # the metric frame the kernel rebuilds from (x / s + c)
+        tgt_m = (it[1] / it[4] + it[7]).double().numpy()
+        Tr, fit, rmse, n_it = icp_ref(src_m, tgt_m, T0[i], 0.1, k, 0.0, 0.0)
+        assert n_it == k and int(iters[i]) == k
+        assert np.linalg.norm(T[i] - Tr) < 1e-4, (k, i, np.linalg.norm(T[i] - Tr))
+        assert abs(fr[i, 0] - fit) < 1e-3 and abs(fr[i, 1] - rmse) < 1e-4
 
 
 def test_evaluate_loader_with_gpu_icp_only_improves():
