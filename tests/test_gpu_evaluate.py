@@ -126,41 +126,52 @@ def test_gpu_icp_vs_oracle_loop():
         assert 1 <= iters[i] <= 30 and abs(int(iters[i]) - n_it) <= 3
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 5])
-def test_gpu_icp_matches_oracle_iteration_by_iteration(k):
-    """The same loop, compared where it is well defined: after exactly k updates (convergence test disabled) from the
-    same start, device and oracle have used the same correspondences and agree to 1e-4 Frobenius -- a per-iteration
-    statement instead of 'both end near the same fixed point'.  (Parity with open3d itself stays UNPINNED: open3d is
-    not in the image; oracle/icp_ref.py restates its published RegistrationICP loop.)"""
+def test_gpu_icp_matches_oracle_iteration_by_iteration():
+    """The same loop, compared where it is well defined: ONE update from the same start uses the same correspondences
+    on both sides, so device and oracle must agree to 1e-4 Frobenius.  The starts are the oracle's own iterates
+    T_0, T_1, ..., T_5 (rounded to the fp32 the device holds), i.e. every step of a real ICP trajectory is checked on
+    its own instead of 'both end near the same fixed point' -- over several steps a handful of points flipping across
+    the 0.1 m radius makes the two fp32/fp64 trajectories drift apart by ~2e-5 per flip, which is not a property of
+    either implementation.  Two-update runs (k = 2) are checked as well.  (Parity with open3d itself stays UNPINNED:
+    open3d is not in the image; oracle/icp_ref.py restates its published RegistrationICP loop.)"""
     from oracle.icp_ref import icp_p2p as icp_ref
     from scream_amd import ops
     from scream_amd.packing import PackedBatch
-    items = [SyntheticPairs(kind, 1, seed0=70 + j)[0] for j, kind in enumerate(("3dmatch", "lo"))]
-    batch = PackedBatch.from_pairs([it[0].to(DEV) for it in items], [it[1].to(DEV) for it in items], None)
-    s = torch.tensor([it[4] for it in items], dtype=torch.float32, device=DEV)
-    c = torch.stack([it[7] for it in items]).to(DEV)
-    rng = np.random.default_rng(k)
-    T0 = []
-    for it in items:
+    base = [SyntheticPairs(kind, 1, seed0=70 + j)[0] for j, kind in enumerate(("3dmatch", "lo"))]
+    n_steps = 6
+    items, starts = [], []
+    rng = np.random.default_rng(5)
+    for it in base:
         Tgt = O.gt_pose_metric(it[2], it[3], it[4], it[7]).double().numpy()
         ang = np.radians(1.5)
         P = np.eye(4)
         P[:3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
         P[:3, 3] = rng.normal(scale=0.015, size=3)
-        T0.append((P @ Tgt).astype(np.float32).astype(np.float64))  # the device starts from the fp32 pose: so does the oracle
-    T0 = np.stack(T0)
-    tgt_row0 = (batch.tgt_row0 - batch.rows_src).contiguous()
-    T, fr, iters = ops.icp_p2p(batch.xyz[: batch.rows_src], batch.xyz[batch.rows_src:], batch.src_row0, batch.src_len_dev,
-                               tgt_row0, batch.tgt_len_dev, s, c, torch.from_numpy(T0).float().to(DEV),
-                               max(batch.src_len), max(batch.tgt_len), 0.1, k, 0.0, 0.0)
-    T, fr, iters = T.cpu().numpy().astype(np.float64), fr.cpu().numpy(), iters.cpu().numpy()
-    for i, it in enumerate(items):
         src_m = (it[0] / it[4] + it[7]).double().numpy()  # the metric frame the kernel rebuilds from (x / s + c)
         tgt_m = (it[1] / it[4] + it[7]).double().numpy()
-        Tr, fit, rmse, n_it = icp_ref(src_m, tgt_m, T0[i], 0.1, k, 0.0, 0.0)
-        assert n_it == k and int(iters[i]) == k
-        assert np.linalg.norm(T[i] - Tr) < 1e-4, (k, i, np.linalg.norm(T[i] - Tr))
-        assert abs(fr[i, 0] - fit) < 1e-3 and abs(fr[i, 1] - rmse) < 1e-4
+        T = P @ Tgt
+        for j in range(n_steps):
+            T32 = T.astype(np.float32).astype(np.float64)
+            items.append((it, src_m, tgt_m))
+            starts.append(T32)
+            T = icp_ref(src_m, tgt_m, T32, 0.1, 1, 0.0, 0.0)[0]  # the oracle's next iterate
+    batch = PackedBatch.from_pairs([it[0][0].to(DEV) for it in items], [it[0][1].to(DEV) for it in items], None)
+    s = torch.tensor([it[0][4] for it in items], dtype=torch.float32, device=DEV)
+    c = torch.stack([it[0][7] for it in items]).to(DEV)
+    tgt_row0 = (batch.tgt_row0 - batch.rows_src).contiguous()
+    T0 = torch.from_numpy(np.stack(starts)).float().to(DEV)
+    for k in (1, 2):
+        T, fr, iters = ops.icp_p2p(batch.xyz[: batch.rows_src], batch.xyz[batch.rows_src:], batch.src_row0, batch.src_len_dev,
+                                   tgt_row0, batch.tgt_len_dev, s, c, T0, max(batch.src_len), max(batch.tgt_len), 0.1, k, 0.0, 0.0)
+        T, fr, iters = T.cpu().numpy().astype(np.float64), fr.cpu().numpy(), iters.cpu().numpy()
+        worst = 0.0
+        for i, (it, src_m, tgt_m) in enumerate(items):
+            Tr, fit, rmse, n_it = icp_ref(src_m, tgt_m, starts[i], 0.1, k, 0.0, 0.0)
+            assert n_it == k and int(iters[i]) == k
+            worst = max(worst, np.linalg.norm(T[i] - Tr))
+            assert np.linalg.norm(T[i] - Tr) < 1e-4, (k, i, np.linalg.norm(T[i] - Tr))
+            assert abs(fr[i, 0] - fit) < 1e-3 and abs(fr[i, 1] - rmse) < 1e-4
+        assert worst > 0.0  # not a comparison of a thing with itself
 
 
 def test_evaluate_loader_with_gpu_icp_only_improves():
