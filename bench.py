@@ -48,6 +48,7 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_BF16_DENSE_TFLOPS = 2500.0  # same table; the split GEMM spends six bf16 MFMAs per fp32 product
 GEMM_NAMES = {0: "gemm<EPI_NONE>", 1: "gemm<EPI_ELU1> (cross-layer q projection)",
               5: "gemm<EPI_QKV> (q/k/v projection + fused K^T V reduce)",
+              6: "ffn_x3_kernel (FFN 256->1024, relu, 1024->256 + residual + LayerNorm in one launch)",
               2: "gemm<EPI_RELU> (FFN 256->1024)", 3: "gemm<EPI_BIAS_RELU> (coor_mlp)",
               4: "gemm<EPI_RES_LN> (merge, FFN 1024->256 + residual + LayerNorm)",
               100: "pe_embed_ln_kernel", 101: "kv_finalize_tiles_kernel", 102: "attn_apply_kernel",
@@ -377,7 +378,7 @@ def main():
         e = by.setdefault(kind[i], {"launches": 0, "ms": 0.0, "padded_flops": 0.0})
         e["launches"] += 1
         e["ms"] += ms[i]
-        e["padded_flops"] += 2.0 * mm[i] * nn[i] * kk[i]
+        e["padded_flops"] += 2.0 * mm[i] * nn[i] * kk[i] * (2 if kind[i] == 6 else 1)  # kind 6 = FFN up AND down
         if kind[i] < 100:
             e2 = by_shape.setdefault((kind[i], mm[i], nn[i], kk[i]), {"launches": 0, "ms": 0.0})
             e2["launches"] += 1
@@ -397,7 +398,7 @@ def main():
         by_kernel.append(row)
     by_gemm_shape = [{"epilogue": k_[0], "M": int(k_[1]), "N": int(k_[2]), "K": int(k_[3]), "launches": v["launches"],
                       "avg_ms": round(v["ms"] / v["launches"], 4),
-                      "tflops_padded": round(2.0 * k_[1] * k_[2] * k_[3] / (v["ms"] / v["launches"] * 1e-3) / 1e12, 1)}
+                      "tflops_padded": round(2.0 * k_[1] * k_[2] * k_[3] * (2 if k_[0] == 6 else 1) / (v["ms"] / v["launches"] * 1e-3) / 1e12, 1)}
                      for k_, v in sorted(by_shape.items())]
 
     x3 = net.gemm_backend == "x3"

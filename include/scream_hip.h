@@ -94,6 +94,18 @@ int scream_gemm_qkv_x3_f32(const float* A, int64_t lda, const void* W_packed, fl
                            const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
                            float* kv_partial, void* stream);
 
+/* ---- A4 (FFN half) as ONE launch: y = LayerNorm(residual + W2 . relu(W1 . m1)), the 1024-wide hidden activations
+ * never leave the register file (scream_amd/csrc/tail_x3.hip: transposed formulation, weights as the MFMA A operand).
+ * Replaces models/transformer.py:66-72,86-88 (mlp = Linear(256,1024,no bias), ReLU, Linear(1024,256,no bias); norm2 of
+ * x + mlp(.)), i.e. scream_gemm_x3_f32(EPI_RELU) followed by scream_gemm_x3_f32(EPI_RES_LN), with the same split-bf16
+ * arithmetic.  scream_pack_ffn_x3 builds the 3 MiB weight image (scream_ffn_image_bytes()) once from W1 [1024,256] and
+ * W2 [256,1024] fp32 (device to device).  m1, residual, y: [M, 256] fp32 with row strides ld* (multiples of 4),
+ * M % 128 == 0; gamma/beta [256]. */
+int64_t scream_ffn_image_bytes(void);
+int scream_pack_ffn_x3(const float* W1, const float* W2, void* ffn_image, void* stream);
+int scream_ffn_x3_f32(const float* m1, int64_t ldm, const void* ffn_image, const float* residual, int64_t ldr,
+                      const float* gamma, const float* beta, float* y, int64_t ldy, int64_t M, void* stream);
+
 /* ---- A1: feats = LayerNorm(PE_sine(xyz) + W_e (xyz - center[cloud]) + b_e)
  * Replaces models/pointnet.py:45-48 (+ models/transformer.py:157-179).  xyz [rows,3] packed;
  * tile_cloud[rows/128] gives the cloud of each 128-row tile; center [n_clouds,3] (zeros for
@@ -138,6 +150,9 @@ typedef struct {
     const float* w2;   /* mlp.2 [256,1024] */
     const float* g1; const float* b1; /* norm1 */
     const float* g2; const float* b2; /* norm2 */
+    /* gemm_planes == 1 only; may be NULL.  scream_pack_ffn_x3 image of (w1, w2): the forward then runs the FFN half of the
+     * block as ONE launch (scream_ffn_x3_f32) instead of FFN-up + FFN-down, and ignores w1 / w2. */
+    const void* ffn;
 } scream_layer_t;
 
 typedef struct {

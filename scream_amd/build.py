@@ -17,6 +17,7 @@ ARCH = "gfx950"
 SOURCES = {
     "gemm_f32.hip": [],
     "gemm_x3.hip": [],
+    "tail_x3.hip": [],
     "embed.hip": [],
     "attention.hip": [],
     "forward.hip": [],

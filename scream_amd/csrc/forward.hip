@@ -74,7 +74,7 @@ struct Scope {  // records start on construction, stop on destruction
         if (rc_ != 0) return rc_; \
     } while (0)
 
-enum { TR_EMBED = 100, TR_KV_REDUCE = 101, TR_ATTN_APPLY = 102, TR_COOR_HEAD = 103 };
+enum { TR_FFN_FUSED = 6, TR_EMBED = 100, TR_KV_REDUCE = 101, TR_ATTN_APPLY = 102, TR_COOR_HEAD = 103 };
 
 struct Ctx {
     void* st;
@@ -106,6 +106,10 @@ int mha_tail(const Ctx& c, const scream_layer_t& L, const Workspace& w, const fl
     float* m1 = w.m1 + row0 * D;
     float* hid = w.hid + row0 * 4 * D;
     TRY(gemm(c, att, D, L.wm, m1, D, rows, D, D, SCREAM_EPI_RES_LN, 0, nullptr, x, L.g1, L.b1));
+    if (c.planes && L.ffn) {  // FFN-up, relu, FFN-down, residual and LayerNorm2 in one launch: the hidden activations stay on chip
+        Scope sc(c.tr, TR_FFN_FUSED, rows, 4 * D, D, c.st);
+        return scream_ffn_x3_f32(m1, D, L.ffn, x, D, L.g2, L.b2, y, D, rows, c.st);
+    }
     TRY(gemm(c, m1, D, L.w1, hid, 4 * D, rows, 4 * D, D, SCREAM_EPI_RELU, 0, nullptr, nullptr, nullptr, nullptr));
     TRY(gemm(c, hid, 4 * D, L.w2, y, D, rows, D, 4 * D, SCREAM_EPI_RES_LN, 0, nullptr, x, L.g2, L.b2));
     return 0;
@@ -151,8 +155,8 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
 
 }  // namespace
 
-extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi6"; }
-extern "C" int scream_abi_version(void) { return 6; }
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi7"; }
+extern "C" int scream_abi_version(void) { return 7; }
 
 extern "C" void* scream_trace_create(int32_t capacity) {
     if (capacity <= 0) return nullptr;

@@ -93,8 +93,12 @@ class PointTransformer(nn.Module):
     # the throughput), "f32" = fp32-input MFMA.  Both are held to the same parity tolerances; SCREAM_GEMM overrides.
     gemm_backend = os.environ.get("SCREAM_GEMM", "x3")
 
+    # x3 only: run FFN-up + relu + FFN-down + residual + LayerNorm2 as one launch (csrc/tail_x3.hip); SCREAM_FUSED_FFN=0
+    # keeps the two GEMM launches (same arithmetic, the hidden activations then go through HBM)
+    fused_ffn = os.environ.get("SCREAM_FUSED_FFN", "1") != "0"
+
     def _signature(self):
-        return (self.gemm_backend,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.gemm_backend, self.fused_ffn) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _pack_weights(self):
         sig = self._signature()
@@ -135,8 +139,15 @@ class PointTransformer(nn.Module):
             L.wq = dev_mat(m.q_proj.weight)
             L.wkv = dev_mat(wkv)
             L.wm = dev_mat(m.merge.weight)
-            L.w1 = dev_mat(m.mlp[0].weight)
-            L.w2 = dev_mat(m.mlp[2].weight)
+            if planes and self.fused_ffn:  # one launch for the FFN half (scream_ffn_x3_f32); w1 / w2 are then unused
+                img = ops.pack_ffn(m.mlp[0].weight.detach().to(device=dev, dtype=torch.float32),
+                                   m.mlp[2].weight.detach().to(device=dev, dtype=torch.float32))
+                keep.append(img)
+                L.ffn, L.w1, L.w2 = img.data_ptr(), None, None
+            else:
+                L.ffn = None
+                L.w1 = dev_mat(m.mlp[0].weight)
+                L.w2 = dev_mat(m.mlp[2].weight)
             L.g1, L.b1 = dev_f32(m.norm1.weight), dev_f32(m.norm1.bias)
             L.g2, L.b2 = dev_f32(m.norm2.weight), dev_f32(m.norm2.bias)
         mt = _lib.ModelT()

@@ -79,6 +79,28 @@ def gemm_x3(A: torch.Tensor, Wp: torch.Tensor, epilogue: int = EPI_NONE, n_act: 
     return out
 
 
+def pack_ffn(W1: torch.Tensor, W2: torch.Tensor) -> torch.Tensor:
+    """mlp.0.weight [1024,256], mlp.2.weight [256,1024] (fp32, on the GPU) -> the weight image of ffn_x3 (uint8)."""
+    W1 = W1.detach().to(torch.float32).contiguous()
+    W2 = W2.detach().to(torch.float32).contiguous()
+    assert W1.shape == (4 * D_MODEL, D_MODEL) and W2.shape == (D_MODEL, 4 * D_MODEL)
+    lib = _lib.load()
+    out = torch.empty(lib.scream_ffn_image_bytes(), device=W1.device, dtype=torch.uint8)
+    check(lib.scream_pack_ffn_x3(_p(W1), _p(W2), _p(out, torch.uint8), _stream()), "scream_pack_ffn_x3")
+    return out
+
+
+def ffn_x3(m1: torch.Tensor, image: torch.Tensor, residual: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm(residual + relu(m1 @ W1.T) @ W2.T) in one launch (scream_ffn_x3_f32); image = pack_ffn(W1, W2)."""
+    M = m1.shape[0]
+    if out is None:
+        out = torch.empty(M, D_MODEL, device=m1.device, dtype=torch.float32)
+    check(_lib.load().scream_ffn_x3_f32(_p(m1), m1.stride(0), _p(image, torch.uint8), _p(residual), residual.stride(0),
+                                        _p(gamma), _p(beta), _p(out), out.stride(0), M, _stream()), "scream_ffn_x3_f32")
+    return out
+
+
 def gemm_qkv(A: torch.Tensor, W: torch.Tensor, n_q: int, tile_cloud, cloud_row0, cloud_len, row_base: int):
     """Fused q/k/v projection (scream_gemm_qkv_f32).  Returns (Q' [M,256] or None, kv_partial [M/128,8,1056])."""
     M, K = A.shape

@@ -537,3 +537,53 @@ def test_kabsch_round_trip_at_65536_correspondences():
     assert float((T - want).flatten(1).norm(dim=1).max()) < 1e-4
     back = torch.linalg.inv(want.double()) @ T.double()
     assert float((back - torch.eye(4, dtype=torch.float64)).flatten(1).norm(dim=1).max()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------- fused FFN (tail_x3.hip)
+def _ffn_reference(m1, W1, W2, x, g, b):
+    h = torch.relu(m1.double() @ W1.double().t())
+    return torch.nn.functional.layer_norm(x.double() + h @ W2.double().t(), (256,), g.double(), b.double(), 1e-5)
+
+
+@pytest.mark.parametrize("M", [128, 384, 33024])
+def test_fused_ffn_vs_float64_and_vs_two_launch_path(M):
+    """y = LayerNorm2(x + W2 relu(W1 m1)) in ONE launch (hidden activations stay in registers, transposed formulation
+    with permuted weight images) against float64, and against the two-GEMM path it replaces (same split-bf16
+    arithmetic, different summation order).  M = 33024 = 258 row tiles: persistent blocks walk several tiles and the
+    weight ring wraps across tile boundaries; asymmetric weights and row-dependent inputs catch any permutation slip."""
+    g_ = torch.Generator().manual_seed(M)
+    m1 = torch.randn(M, 256, generator=g_)
+    x = torch.randn(M, 256, generator=g_) * 2
+    W1 = torch.randn(1024, 256, generator=g_) / 16
+    W2 = torch.randn(256, 1024, generator=g_) / 32
+    g = torch.rand(256, generator=g_) + 0.5
+    b = torch.randn(256, generator=g_)
+    img = ops.pack_ffn(dev(W1), dev(W2))
+    out = ops.ffn_x3(dev(m1), img, dev(x), dev(g), dev(b)).cpu()
+    want = _ffn_reference(m1, W1, W2, x, g, b)
+    torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=2e-5)
+    hid = ops.gemm_x3(dev(m1), ops.split_planes(dev(W1)), ops.EPI_RELU)
+    two = ops.gemm_x3(hid, ops.split_planes(dev(W2)), ops.EPI_RES_LN, residual=dev(x), gamma=dev(g), beta=dev(b)).cpu()
+    err_fused, err_two = (out.double() - want).abs().max().item(), (two.double() - want).abs().max().item()
+    assert err_fused <= 2.0 * err_two + 1e-6, (err_fused, err_two)
+    # row-offset views (the forward hands in slices of its workspace): same result
+    big = torch.zeros(M + 256, 256, device=DEV)
+    big[128:128 + M] = dev(m1)
+    out2 = ops.ffn_x3(big[128:128 + M], img, dev(x), dev(g), dev(b))
+    assert torch.equal(out2.cpu(), out)
+
+
+def test_fused_ffn_identity_weights_expose_the_permutation():
+    """W1 = [I; 0] and W2 = [diag(1..256), 0]: y = LN(x + m1 * (1..256)) for m1 >= 0 -- every hidden unit and every
+    output feature carries a distinct tag, so a wrong row/column mapping in the packed images cannot cancel out."""
+    M = 128
+    m1 = torch.rand(M, 256) + torch.arange(M)[:, None] / M
+    x = torch.zeros(M, 256)
+    W1 = torch.zeros(1024, 256)
+    W1[:256] = torch.eye(256)
+    W2 = torch.zeros(256, 1024)
+    W2[:, :256] = torch.diag(torch.arange(1, 257, dtype=torch.float32))
+    g, b = torch.ones(256), torch.zeros(256)
+    out = ops.ffn_x3(dev(m1), ops.pack_ffn(dev(W1), dev(W2)), dev(x), dev(g), dev(b)).cpu()
+    want = _ffn_reference(m1, W1, W2, x, g, b)
+    torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=1e-5)
