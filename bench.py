@@ -49,6 +49,7 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0  # same table; the split GEMM spends six bf16 MF
 GEMM_NAMES = {0: "gemm<EPI_NONE>", 1: "gemm<EPI_ELU1> (cross-layer q projection)",
               5: "gemm<EPI_QKV> (q/k/v projection + fused K^T V reduce)",
               6: "ffn_x3_kernel (FFN 256->1024, relu, 1024->256 + residual + LayerNorm in one launch)",
+              7: "tail_x3_kernel (attention apply, merge + LayerNorm1, FFN + LayerNorm2 in one launch; N = 256 + 2 x 1024 columns)",
               2: "gemm<EPI_RELU> (FFN 256->1024)", 3: "gemm<EPI_BIAS_RELU> (coor_mlp)",
               4: "gemm<EPI_RES_LN> (merge, FFN 1024->256 + residual + LayerNorm)",
               100: "pe_embed_ln_kernel", 101: "kv_finalize_tiles_kernel", 102: "attn_apply_kernel",

@@ -46,6 +46,19 @@ enum {
     SCREAM_EPI_QKV = 5        /* internal to scream_gemm_qkv_f32 */
 };
 
+/* ---- Activation layouts of a [M, 256] fp32 matrix (M % 32 == 0).
+ * Row-major is the default everywhere.  FRAGMENT-major (SCREAM_ACT_FRAG) is the layout the split-bf16 kernels pass
+ * between each other inside scream_forward: element (row 32 t + r, feature 32 blk + 8 a + 4 h + b) -- t the 32-row group,
+ * blk the 32-feature segment, a in 0..3, h in 0..1, b in 0..3 -- lives at float offset
+ *     ((((t * 8 + blk) * 4 + a) * 64 + r + 32 h) * 4 + b.
+ * A 32-row group occupies the same 32 KiB as in row-major, so slices of whole groups are the same pointers in both
+ * layouts.  Why: lane r + 32 h of a wave owns exactly the 16-byte pieces 2a + h of every 128-byte segment of row r as an
+ * MFMA operand; stored this way, each of its four loads per segment is one fully contiguous 1 KiB wave access instead of
+ * 32 half-used cache lines (scream_amd/csrc/tail_x3.hip).  scream_act_layout converts a matrix between the two. */
+#define SCREAM_LAYOUT_A_FRAG 1 /* the GEMM's A operand is fragment-major */
+#define SCREAM_LAYOUT_C_FRAG 2 /* the activated (elu + 1) query tile of the GEMM's output is fragment-major */
+int scream_act_layout(const float* src, float* dst, int64_t M, int32_t to_fragment, void* stream);
+
 /* Library / build identification: "scream_hip gfx950 <abi>"; abi bumps on any signature change. */
 const char* scream_version(void);
 int scream_abi_version(void);
@@ -93,6 +106,16 @@ int scream_gemm_qkv_x3_f32(const float* A, int64_t lda, const void* W_packed, fl
                            int64_t M, int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
                            const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
                            float* kv_partial, void* stream);
+/* The same two with an explicit activation layout (SCREAM_LAYOUT_* bits): A fragment-major needs lda == K == 256;
+ * C fragment-major applies to the activated tile of an ELU1 / QKV epilogue with n_act == ldc == 256 (the queries). */
+int scream_gemm_x3_ex_f32(const float* A, int64_t lda, const void* W_packed, float* C, int64_t ldc, int64_t M,
+                          int32_t N, int32_t K, int32_t epilogue, int32_t n_act, const float* bias,
+                          const float* residual, int64_t ldr, const float* gamma, const float* beta,
+                          int32_t layout, void* stream);
+int scream_gemm_qkv_x3_ex_f32(const float* A, int64_t lda, const void* W_packed, float* Q, int64_t ldq,
+                              int64_t M, int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
+                              const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
+                              float* kv_partial, int32_t layout, void* stream);
 
 /* ---- A4 (FFN half) as ONE launch: y = LayerNorm(residual + W2 . relu(W1 . m1)), the 1024-wide hidden activations
  * never leave the register file (scream_amd/csrc/tail_x3.hip: transposed formulation, weights as the MFMA A operand).
@@ -105,6 +128,32 @@ int64_t scream_ffn_image_bytes(void);
 int scream_pack_ffn_x3(const float* W1, const float* W2, void* ffn_image, void* stream);
 int scream_ffn_x3_f32(const float* m1, int64_t ldm, const void* ffn_image, const float* residual, int64_t ldr,
                       const float* gamma, const float* beta, float* y, int64_t ldy, int64_t M, void* stream);
+
+/* ---- A3 (apply) + A4 as ONE launch: everything of an MHAttention block that is local to a row,
+ *     att = ((Q' . KV) * Z) * S;  m1 = LayerNorm1(att . Wm^T + x);  y = LayerNorm2(x + W2 . relu(W1 . m1))
+ * Replaces models/transformer.py:41-42,83-88, i.e. scream_attn_apply + scream_gemm_x3_f32(merge, EPI_RES_LN) +
+ * scream_ffn_x3_f32, with the same split-bf16 arithmetic; att, m1 and the hidden activations never reach memory
+ * (scream_amd/csrc/tail_x3.hip).  Operands:
+ * Q, x and y are FRAGMENT-major [M, 256] matrices (SCREAM_ACT_FRAG above; scream_act_layout converts):
+ *   Q             the elu+1 mapped queries written by scream_gemm_qkv_x3_ex_f32 / scream_gemm_x3_ex_f32(EPI_ELU1) with
+ *                 SCREAM_LAYOUT_C_FRAG;
+ *   kv_image      scream_kv_image_bytes() per cloud, written by scream_kv_finalize_x3 from the K^T V partials of
+ *                 scream_gemm_qkv_x3_f32 (same arguments as scream_kv_finalize): KV^T / S as MFMA operand fragments in
+ *                 three bf16 planes + Ksum in fp32;  the key cloud of 128-row tile t is tile_cloud[t] + kv_cloud_offset
+ *                 (tile_cloud points at the entry of the first row), cloud_len gives S;
+ *   x             the block input (residual of BOTH norms), must not alias y;
+ *   tail_image    scream_tail_image_bytes(), built once by scream_pack_tail_x3 from merge [256,256], mlp.0 [1024,256]
+ *                 and mlp.2 [256,1024] (fp32, device to device).
+ * M % 128 == 0, every pointer 16-byte aligned. */
+int64_t scream_tail_image_bytes(void);
+int64_t scream_kv_image_bytes(void);
+int scream_pack_tail_x3(const float* Wm, const float* W1, const float* W2, void* tail_image, void* stream);
+int scream_kv_finalize_x3(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
+                          int64_t row_base, int32_t cloud_begin, int32_t n_kv, void* kv_image, void* stream);
+int scream_layer_tail_x3_f32(const float* Q, const void* kv_image, const int32_t* tile_cloud,
+                             int32_t kv_cloud_offset, const int32_t* cloud_len, const float* x,
+                             const void* tail_image, const float* g1, const float* b1, const float* g2,
+                             const float* b2, float* y, int64_t M, void* stream);
 
 /* ---- A1: feats = LayerNorm(PE_sine(xyz) + W_e (xyz - center[cloud]) + b_e)
  * Replaces models/pointnet.py:45-48 (+ models/transformer.py:157-179).  xyz [rows,3] packed;
@@ -153,6 +202,10 @@ typedef struct {
     /* gemm_planes == 1 only; may be NULL.  scream_pack_ffn_x3 image of (w1, w2): the forward then runs the FFN half of the
      * block as ONE launch (scream_ffn_x3_f32) instead of FFN-up + FFN-down, and ignores w1 / w2. */
     const void* ffn;
+    /* gemm_planes == 1 only; may be NULL.  scream_pack_tail_x3 image of (wm, w1, w2): the forward then runs attention
+     * apply, merge + norm1 and the FFN + norm2 as ONE launch per block (scream_layer_tail_x3_f32) and ignores wm, w1, w2
+     * and ffn. */
+    const void* tail;
 } scream_layer_t;
 
 typedef struct {

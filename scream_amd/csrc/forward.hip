@@ -17,6 +17,7 @@ constexpr int KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;
 
 struct Workspace {
     float *x0, *x1, *q, *att, *m1, *hid, *kvp, *kv;
+    char* kvimg;  // per-cloud operand images of the fused layer tail
     int64_t bytes;
 };
 
@@ -36,6 +37,7 @@ Workspace carve(void* base, int64_t rows_total, int32_t n_pairs, int32_t max_chu
     w.hid = take(rows_total * 4 * D);
     w.kvp = take(rows_total / SCREAM_ROW_TILE * SCREAM_NHEAD * KV_ELEMS);  // one K^T V partial per 128-row tile and head
     w.kv = take((int64_t)2 * n_pairs * SCREAM_NHEAD * KV_ELEMS);
+    w.kvimg = reinterpret_cast<char*>(take((int64_t)2 * n_pairs * scream_kv_image_bytes() / 4));
     w.bytes = (p - reinterpret_cast<float*>(base)) * (int64_t)sizeof(float);
     return w;
 }
@@ -74,18 +76,19 @@ struct Scope {  // records start on construction, stop on destruction
         if (rc_ != 0) return rc_; \
     } while (0)
 
-enum { TR_FFN_FUSED = 6, TR_EMBED = 100, TR_KV_REDUCE = 101, TR_ATTN_APPLY = 102, TR_COOR_HEAD = 103 };
+enum { TR_FFN_FUSED = 6, TR_TAIL_FUSED = 7, TR_EMBED = 100, TR_KV_REDUCE = 101, TR_ATTN_APPLY = 102, TR_COOR_HEAD = 103 };
 
 struct Ctx {
     void* st;
     Trace* tr;
     bool planes;  // scream_model_t.gemm_planes: weights are bf16 plane blocks, GEMMs on the split kernel
+    bool frag;    // every layer has a fused-tail image: the features travel FRAGMENT-major between the kernels (SCREAM_ACT_FRAG)
 };
 
 int gemm(const Ctx& c, const float* A, int64_t lda, const float* W, float* C, int64_t ldc, int64_t M, int N, int K,
-         int epi, int n_act, const float* bias, const float* res, const float* g, const float* b) {
+         int epi, int n_act, const float* bias, const float* res, const float* g, const float* b, int layout = 0) {
     Scope sc(c.tr, epi, M, N, K, c.st);
-    if (c.planes) return scream_gemm_x3_f32(A, lda, W, C, ldc, M, N, K, epi, n_act, bias, res, D, g, b, c.st);
+    if (c.planes) return scream_gemm_x3_ex_f32(A, lda, W, C, ldc, M, N, K, epi, n_act, bias, res, D, g, b, layout, c.st);
     return scream_gemm_f32(A, lda, W, C, ldc, M, N, K, epi, n_act, bias, res, D, g, b, c.st);
 }
 
@@ -93,8 +96,8 @@ int gemm_qkv(const Ctx& c, const float* A, const float* W, float* Q, int64_t M, 
              int64_t row_base, float* kvp) {
     Scope sc(c.tr, 5, M, N, D, c.st);
     if (c.planes)
-        return scream_gemm_qkv_x3_f32(A, D, W, Q, D, M, N, D, n_q, b.tile_cloud, b.cloud_row0, b.cloud_len, row_base, kvp,
-                                      c.st);
+        return scream_gemm_qkv_x3_ex_f32(A, D, W, Q, D, M, N, D, n_q, b.tile_cloud, b.cloud_row0, b.cloud_len, row_base, kvp,
+                                         c.frag ? (SCREAM_LAYOUT_A_FRAG | (n_q ? SCREAM_LAYOUT_C_FRAG : 0)) : 0, c.st);
     return scream_gemm_qkv_f32(A, D, W, Q, D, M, N, D, n_q, b.tile_cloud, b.cloud_row0, b.cloud_len, row_base, kvp, c.st);
 }
 
@@ -124,6 +127,15 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
     float* qr = w.q + row0 * D;
     float* kvp = w.kvp + row0 / SCREAM_ROW_TILE * SCREAM_NHEAD * KV_ELEMS;
     TRY(gemm_qkv(c, xr, L.wqkv, qr, rows, 3 * D, D, b, row0, kvp));
+    if (c.frag) {  // apply + merge + norm1 + FFN + norm2 in one launch
+        {
+            Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
+            TRY(scream_kv_finalize_x3(kvp, b.cloud_row0, b.cloud_len, row0, cloud_begin, n_clouds, w.kvimg, c.st));
+        }
+        Scope sc(c.tr, TR_TAIL_FUSED, rows, 9 * D, D, c.st);  // merge (256) + FFN up and down (2 x 1024) output columns per row
+        return scream_layer_tail_x3_f32(qr, w.kvimg, b.tile_cloud + row0 / SCREAM_ROW_TILE, 0, b.cloud_len, xr, L.tail, L.g1,
+                                        L.b1, L.g2, L.b2, y + row0 * D, rows, c.st);
+    }
     {
         Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
         TRY(scream_kv_finalize(kvp, b.cloud_row0, b.cloud_len, row0, cloud_begin, n_clouds, w.kv, c.st));
@@ -140,8 +152,18 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
 int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x_src,
               const float* x_tgt, float* y) {
     const int64_t rs = b.rows_src, rt = b.rows_total - b.rows_src;
-    TRY(gemm(c, x_src, D, L.wq, w.q, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr));
+    TRY(gemm(c, x_src, D, L.wq, w.q, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr,
+             c.frag ? (SCREAM_LAYOUT_A_FRAG | SCREAM_LAYOUT_C_FRAG) : 0));
     TRY(gemm_qkv(c, x_tgt, L.wkv, nullptr, rt, 2 * D, 0, b, rs, w.kvp));
+    if (c.frag) {
+        {
+            Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
+            TRY(scream_kv_finalize_x3(w.kvp, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs, w.kvimg, c.st));
+        }
+        Scope sc(c.tr, TR_TAIL_FUSED, rs, 9 * D, D, c.st);
+        return scream_layer_tail_x3_f32(w.q, w.kvimg, b.tile_cloud, b.n_pairs, b.cloud_len, x_src, L.tail, L.g1, L.b1, L.g2, L.b2,
+                                        y, rs, c.st);
+    }
     {
         Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
         TRY(scream_kv_finalize(w.kvp, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs, w.kv, c.st));
@@ -155,8 +177,8 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
 
 }  // namespace
 
-extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi7"; }
-extern "C" int scream_abi_version(void) { return 7; }
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi9"; }
+extern "C" int scream_abi_version(void) { return 9; }
 
 extern "C" void* scream_trace_create(int32_t capacity) {
     if (capacity <= 0) return nullptr;
@@ -231,12 +253,20 @@ extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t*
     uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
     const Workspace w = carve(reinterpret_cast<void*>(base), b.rows_total, b.n_pairs, b.max_chunks);
     SCREAM_REQUIRE((int64_t)(base - reinterpret_cast<uintptr_t>(workspace)) + w.bytes <= workspace_bytes, SCREAM_EINVAL);
-    const Ctx c{stream, reinterpret_cast<Trace*>(trace), m.gemm_planes != 0};
+    // fragment-major features between the kernels iff EVERY layer carries a fused-tail image (all or none)
+    int n_layers = m.n_self + 2 * m.n_cross, n_tail = 0;
+    for (int i = 0; i < n_layers; ++i) n_tail += m.layers_host[i].tail != nullptr;
+    if (m.stem_tgt_layers_host)
+        for (int i = 0; i < m.n_self; ++i, ++n_layers) n_tail += m.stem_tgt_layers_host[i].tail != nullptr;
+    SCREAM_REQUIRE(n_tail == 0 || (n_tail == n_layers && m.gemm_planes == 1), SCREAM_EINVAL);
+    const Ctx c{stream, reinterpret_cast<Trace*>(trace), m.gemm_planes != 0, n_tail > 0};
 
     const int64_t rs = b.rows_src, ra = b.rows_total;
     {
         Scope sc(c.tr, TR_EMBED, ra, 0, 0, stream);
-        TRY(scream_pe_embed_ln(b.xyz, b.tile_cloud, b.center, m.dim_t, m.emb_w, m.emb_b, m.pre_g, m.pre_b, w.x0, ra, stream));
+        TRY(scream_pe_embed_ln(b.xyz, b.tile_cloud, b.center, m.dim_t, m.emb_w, m.emb_b, m.pre_g, m.pre_b, c.frag ? w.x1 : w.x0, ra,
+                               stream));
+        if (c.frag) TRY(scream_act_layout(w.x1, w.x0, ra, 1, stream));
     }
     float* cur = w.x0;
     float* nxt = w.x1;
@@ -264,13 +294,16 @@ extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t*
         nxt = t;
     }
     // coor_mlp, pointnet.py:27-33,60
-    TRY(gemm(c, cur, D, m.c0_w, w.m1, D, rs, D, D, SCREAM_EPI_BIAS_RELU, 0, m.c0_b, nullptr, nullptr, nullptr));
+    TRY(gemm(c, cur, D, m.c0_w, w.m1, D, rs, D, D, SCREAM_EPI_BIAS_RELU, 0, m.c0_b, nullptr, nullptr, nullptr,
+             c.frag ? SCREAM_LAYOUT_A_FRAG : 0));  // the output (and everything behind it) is row-major
     TRY(gemm(c, w.m1, D, m.c2_w, w.att, D, rs, D, D, SCREAM_EPI_BIAS_RELU, 0, m.c2_b, nullptr, nullptr, nullptr));
     {
         Scope sc(c.tr, TR_COOR_HEAD, rs, 0, 0, stream);
         TRY(scream_coor_head(w.att, m.c4_w, m.c4_b, src_pred, rs, stream));
     }
-    if (feats_out) {
+    if (feats_out && c.frag) {
+        TRY(scream_act_layout(cur, feats_out, rs, 0, stream));
+    } else if (feats_out) {
         hipError_t e = hipMemcpyAsync(feats_out, cur, (size_t)rs * D * sizeof(float), hipMemcpyDeviceToDevice,
                                       as_stream(stream));
         if (e != hipSuccess) return (int)e;

@@ -19,6 +19,9 @@ struct EpiArgs {
     const int32_t* cloud_row0;
     const int32_t* cloud_len;
     int64_t row_base;           // packed row of A's row 0
+    // SCREAM_EPI_ELU1 / SCREAM_EPI_QKV, x3 kernel only: the activated tile (the 256 query columns) is written in the
+    // FRAGMENT-major activation layout (SCREAM_ACT_FRAG, include/scream_hip.h) that tail_x3.hip reads; ldc must be 256
+    int c_frag;
 };
 
 constexpr int KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;
@@ -94,6 +97,39 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[8], float* slabs, in
             }
             lds_barrier();
         }
+    } else if ((EPI == SCREAM_EPI_ELU1 || EPI == SCREAM_EPI_QKV) && NWAVES == 8 && ep.c_frag && n0_cur < ep.n_act) {
+    // ---- Q' = elu(q) + 1 in the fragment-major layout -------------------------------------------------------------
+    // Element (row 32 t + rho, feature 32 blk + 8 a + 4 hf + b) lives at ((((t * 8 + blk) * 4 + a) * 64 + rho + 32 hf) * 4 + b:
+    // per 32-row group, segment and a, one 1 KiB run in lane order -- what a wave of tail_x3.hip loads with one instruction.
+    // Eight rows at a time go through the wave's slab (row-major, the 16-byte chunks of row i XOR-swizzled by i so that the
+    // transposing read below is 2-way conflicted at worst); a store instruction then writes eight full 128-byte lines.
+    if (rows_exist) {
+        float* slab = slabs + wave * (8 * 256);
+        float* cg = C + (m0_cur + wave * 32) * 256;  // this wave's 32-row group (8192 floats in either layout)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // rows 8g .. 8g+7 of the wave's 32
+#pragma unroll
+            for (int tn = 0; tn < 8; ++tn)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int i8 = i + 4 * half;
+                    slab[i8 * 256 + (((tn * 8 + (r >> 2)) ^ i8) << 2) + (r & 3)] = acc[tn][4 * g + i];
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int a = lane >> 4, hf = (lane >> 3) & 1, rr = lane & 7;
+#pragma unroll
+            for (int blk = 0; blk < 8; ++blk) {
+                f32x4 v = ld4(slab + rr * 256 + (((8 * blk + 2 * a + hf) ^ rr) << 2));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] + 1.0f : expf(v[c]);  // elu(x)+1 == exp(x), x <= 0
+                *reinterpret_cast<f32x4*>(cg + ((blk * 4 + a) * 64 + 8 * g + rr + 32 * hf) * 4) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     } else if (rows_exist) {
     // ---- epilogue (wave-private) ---------------------------------------------------------------------------
     // acc[tn][e]: row = wave*32 + mfma32_row(e, half), col = tn*32 + r.  The k-loop ended on a barrier and its

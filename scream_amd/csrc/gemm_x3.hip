@@ -15,9 +15,13 @@
 //     in LDS: [3 planes][K/32][N][32] bf16, rows of 64 B whose 16-byte chunk c lives at c ^ ((n >> 2) & 3) so that the 16
 //     lanes of a ds_read_b128 group cover 16 distinct bank slots.  A k-tile stage is 48 one-KiB LDS-DMA pieces of
 //     CONTIGUOUS memory (with a plain [N][K] plane every piece touched 16 lines for half their bytes); double buffered.
-//   * A stays fp32 in HBM: lane (r, half) streams its 64 contiguous bytes of row r per k-tile straight into registers
-//     (three register sets, requested TWO k-tiles ahead) and splits them there (v_cvt_pk_bf16_f32 + subtract, twice).
-//     Lane-half h owns k = 16h + 8s + j of step s for both operands.
+//   * A stays fp32 in HBM: lane (r, half) streams its 16 floats of row r per k-tile straight into registers (three
+//     register sets, requested TWO k-tiles ahead) and splits them there (v_cvt_pk_bf16_f32 + subtract, twice).
+//     Lane-half h owns k = 8 (2 s + (j >> 2)) + 4 h + (j & 3) of step s for both operands (the contraction index is a
+//     dummy; this is the ownership of a transposed accumulator tile in tail_x3.hip, so the two kernels share one
+//     activation layout).  Two layouts of A: row-major (the four 16-byte pieces 2a + h of the lane's 128-byte segment),
+//     or FRAGMENT-major (SCREAM_ACT_FRAG, include/scream_hip.h): the same pieces stored [32-row group][segment][a][lane],
+//     so that every wave instruction reads 1 KiB of contiguous memory instead of 32 half-used lines.
 //   * One barrier per k-tile with COUNTED waits: requests are issued in a fixed order (D(kt+1), then A(kt+2), pinned
 //     with sched_barrier) so that s_waitcnt vmcnt(4) at the barrier covers the W stage and leaves the A loads of the
 //     k-tile after next in flight; the barrier is followed directly by MFMAs (the first step's operand split was done
@@ -92,7 +96,7 @@ __device__ __forceinline__ void ring_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
-template <int EPI>
+template <int EPI, bool AFRAG>
 __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __restrict__ A, int64_t lda,
                                                              const __bf16* __restrict__ Wp, float* __restrict__ C,
                                                              int64_t ldc, int64_t M, int n_tiles, unsigned total_tiles,
@@ -123,7 +127,10 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
         }
     };
     // A: rows past M (a trailing 128-row half tile) are clamped to the tile's first row and never stored
-    auto a_ptr = [&](int64_t m0, bool ok) { return A + (ok ? m0 + wave * 32 + r : m0) * lda + half * 16; };
+    auto a_ptr = [&](int64_t m0, bool ok) {
+        if (AFRAG) return A + (ok ? m0 + wave * 32 : m0) * lda + lane * 4;  // the wave's 32-row group, piece a = 0 of this lane
+        return A + (ok ? m0 + wave * 32 + r : m0) * lda + half * 4;
+    };
     int boff[2];  // byte offset of this lane's 16-byte chunk of row r for step s (swizzled)
 #pragma unroll
     for (int s = 0; s < 2; ++s) boff[s] = r * 64 + (((2 * half + s) ^ ((r >> 2) & 3)) << 4);
@@ -143,11 +150,19 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
     // the loop back edge and falls back to vmcnt(0) in front of the first use of these registers.  Every use below
     // sits behind an explicit counted s_waitcnt followed by an empty asm on the register (which pins the order).
     auto load_a = [&](f32x4 (&a)[4], int kt) {
-        const float* p = ga + kt * XBK;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[0]) : "v"(p));
-        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(a[1]) : "v"(p));
-        asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(a[2]) : "v"(p));
-        asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(a[3]) : "v"(p));
+        if (AFRAG) {  // segment kt of the group: [a][lane][4 floats], 1 KiB per wave instruction
+            const float* p = ga + kt * (4 * 64 * 4);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[0]) : "v"(p));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(a[1]) : "v"(p));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(a[2]) : "v"(p));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(a[3]) : "v"(p));
+        } else {      // pieces 2a + half of the lane's 128-byte row segment
+            const float* p = ga + kt * XBK;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[0]) : "v"(p));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(a[1]) : "v"(p));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(a[2]) : "v"(p));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:96" : "=v"(a[3]) : "v"(p));
+        }
     };
     // first requests of an output tile, D(0), A(0), A(1) (its first barrier drains the queue; the order is kept pinned)
     auto request_first = [&]() {
@@ -315,17 +330,19 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
     }
 }
 
-// W [N][K] fp32 -> packed planes [3][K/32][N][32] bf16; 16-byte chunk c of a row's 32-deep k-slice is stored at
-// chunk c ^ ((n >> 2) & 3).  One thread per (n, k-tile, stored chunk).
+// W [N][K] fp32 -> packed planes [3][K/32][N][32] bf16.  Logical chunk c = 2 half + s of a row's 32-deep k-slice holds
+// the eight contraction indices lane-half `half` owns in step s, k = 8 (2 s + (j >> 2)) + 4 half + (j & 3), and is stored
+// at chunk c ^ ((n >> 2) & 3).  One thread per (n, k-tile, stored chunk).
 __global__ void pack_w_x3_kernel(const float* __restrict__ W, int N, int K, __bf16* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int KT = K / XBK;
     if (t >= (int64_t)N * KT * 4) return;
     const int cs = (int)(t & 3), n = (int)((t >> 2) % N), kt = (int)((t >> 2) / N);
     const int c = cs ^ ((n >> 2) & 3);
-    const float* src = W + (int64_t)n * K + kt * XBK + c * 8;
+    const int hf = c >> 1, st = c & 1;
+    const float* src = W + (int64_t)n * K + kt * XBK + 16 * st + 4 * hf;  // j = 0..3 here, j = 4..7 eight floats on
     bf16x8 p0, p1, p2;
-    split3(ld4(src), ld4(src + 4), p0, p1, p2);
+    split3(ld4(src), ld4(src + 8), p0, p1, p2);
     const int64_t plane = (int64_t)KT * N * XBK;
     __bf16* dst = out + ((int64_t)kt * N + n) * XBK + cs * 8;
     *reinterpret_cast<bf16x8*>(dst) = p0;
@@ -335,14 +352,18 @@ __global__ void pack_w_x3_kernel(const float* __restrict__ W, int N, int K, __bf
 
 template <int EPI>
 int launch_x3(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, int64_t M, int N, int K,
-              const EpiArgs& ep, hipStream_t st) {
+              const EpiArgs& ep, hipStream_t st, bool a_frag = false) {
     const int n_tiles = N / XBN;
     const int64_t total = ((M + XBM - 1) / XBM) * n_tiles;
     if (total == 0) return 0;
     SCREAM_REQUIRE(total < (1ll << 31), SCREAM_EUNSUPPORTED);
     const unsigned grid = total < X_MAX_GRID ? (unsigned)total : (unsigned)X_MAX_GRID;
-    gemm_x3_kernel<EPI><<<dim3(grid), dim3(XTHREADS), 0, st>>>(A, lda, reinterpret_cast<const __bf16*>(Wp), C, ldc, M,
-                                                               n_tiles, (unsigned)total, N, K, ep);
+    if (a_frag)
+        gemm_x3_kernel<EPI, true><<<dim3(grid), dim3(XTHREADS), 0, st>>>(A, lda, reinterpret_cast<const __bf16*>(Wp), C, ldc, M,
+                                                                         n_tiles, (unsigned)total, N, K, ep);
+    else
+        gemm_x3_kernel<EPI, false><<<dim3(grid), dim3(XTHREADS), 0, st>>>(A, lda, reinterpret_cast<const __bf16*>(Wp), C, ldc, M,
+                                                                          n_tiles, (unsigned)total, N, K, ep);
     SCREAM_LAUNCH_CHECK();
     return 0;
 }
@@ -360,49 +381,79 @@ extern "C" int scream_pack_w_x3(const float* W, int32_t N, int32_t K, void* pack
     return 0;
 }
 
-extern "C" int scream_gemm_x3_f32(const float* A, int64_t lda, const void* W_planes, float* C, int64_t ldc, int64_t M,
-                                  int32_t N, int32_t K, int32_t epilogue, int32_t n_act, const float* bias,
-                                  const float* residual, int64_t ldr, const float* gamma, const float* beta,
-                                  void* stream) {
+// layout bit 0 (SCREAM_LAYOUT_A_FRAG): A is fragment-major (K == 256 == lda); bit 1 (SCREAM_LAYOUT_C_FRAG): the activated
+// tile of an ELU1 / QKV epilogue (the 256 query columns) is written fragment-major (ldc == 256 == n_act)
+static int check_layout(int32_t layout, int64_t lda, int64_t ldc, int32_t K, int32_t epilogue, int32_t n_act) {
+    SCREAM_REQUIRE((layout & ~3) == 0, SCREAM_EINVAL);
+    if (layout & SCREAM_LAYOUT_A_FRAG) SCREAM_REQUIRE(lda == SCREAM_D_MODEL && K == SCREAM_D_MODEL, SCREAM_EUNSUPPORTED);
+    if (layout & SCREAM_LAYOUT_C_FRAG)
+        SCREAM_REQUIRE(ldc == SCREAM_D_MODEL && n_act == SCREAM_D_MODEL && (epilogue == SCREAM_EPI_ELU1 || epilogue == SCREAM_EPI_QKV), SCREAM_EUNSUPPORTED);
+    return 0;
+}
+
+extern "C" int scream_gemm_x3_ex_f32(const float* A, int64_t lda, const void* W_planes, float* C, int64_t ldc, int64_t M,
+                                     int32_t N, int32_t K, int32_t epilogue, int32_t n_act, const float* bias,
+                                     const float* residual, int64_t ldr, const float* gamma, const float* beta,
+                                     int32_t layout, void* stream) {
     SCREAM_REQUIRE(A && W_planes && C, SCREAM_EINVAL);
     SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K >= 64 && K % 64 == 0 && (K / 32 - 2) % 3 == 0, SCREAM_EUNSUPPORTED);  // K = 64 + 192 j: an EVEN number of k-tiles (stage = kt & 1), in groups of three after the first two
     SCREAM_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0 && ldc % 4 == 0, SCREAM_EINVAL);
     SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W_planes) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(C) & 15) == 0, SCREAM_EINVAL);
-    EpiArgs ep{n_act, bias, residual, ldr, gamma, beta, nullptr, nullptr, nullptr, nullptr, 0};
+    if (int rc = check_layout(layout, lda, ldc, K, epilogue, n_act)) return rc;
+    const bool af = layout & SCREAM_LAYOUT_A_FRAG;
+    EpiArgs ep{n_act, bias, residual, ldr, gamma, beta, nullptr, nullptr, nullptr, nullptr, 0, (layout & SCREAM_LAYOUT_C_FRAG) ? 1 : 0};
     hipStream_t st = as_stream(stream);
     switch (epilogue) {
         case SCREAM_EPI_NONE:
-            return launch_x3<SCREAM_EPI_NONE>(A, lda, W_planes, C, ldc, M, N, K, ep, st);
+            return launch_x3<SCREAM_EPI_NONE>(A, lda, W_planes, C, ldc, M, N, K, ep, st, af);
         case SCREAM_EPI_ELU1:
             SCREAM_REQUIRE(n_act >= 0 && n_act % XBN == 0, SCREAM_EUNSUPPORTED);
-            return launch_x3<SCREAM_EPI_ELU1>(A, lda, W_planes, C, ldc, M, N, K, ep, st);
+            return launch_x3<SCREAM_EPI_ELU1>(A, lda, W_planes, C, ldc, M, N, K, ep, st, af);
         case SCREAM_EPI_RELU:
-            return launch_x3<SCREAM_EPI_RELU>(A, lda, W_planes, C, ldc, M, N, K, ep, st);
+            return launch_x3<SCREAM_EPI_RELU>(A, lda, W_planes, C, ldc, M, N, K, ep, st, af);
         case SCREAM_EPI_BIAS_RELU:
             SCREAM_REQUIRE(bias, SCREAM_EINVAL);
-            return launch_x3<SCREAM_EPI_BIAS_RELU>(A, lda, W_planes, C, ldc, M, N, K, ep, st);
+            return launch_x3<SCREAM_EPI_BIAS_RELU>(A, lda, W_planes, C, ldc, M, N, K, ep, st, af);
         case SCREAM_EPI_RES_LN:
             SCREAM_REQUIRE(N == XBN, SCREAM_EUNSUPPORTED);
             SCREAM_REQUIRE(residual && gamma && beta && ldr >= N && ldr % 4 == 0, SCREAM_EINVAL);
             SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(residual) & 15) == 0, SCREAM_EINVAL);
-            return launch_x3<SCREAM_EPI_RES_LN>(A, lda, W_planes, C, ldc, M, N, K, ep, st);
+            return launch_x3<SCREAM_EPI_RES_LN>(A, lda, W_planes, C, ldc, M, N, K, ep, st, af);
         default:
             return SCREAM_EINVAL;
     }
+}
+
+extern "C" int scream_gemm_x3_f32(const float* A, int64_t lda, const void* W_planes, float* C, int64_t ldc, int64_t M,
+                                  int32_t N, int32_t K, int32_t epilogue, int32_t n_act, const float* bias,
+                                  const float* residual, int64_t ldr, const float* gamma, const float* beta,
+                                  void* stream) {
+    return scream_gemm_x3_ex_f32(A, lda, W_planes, C, ldc, M, N, K, epilogue, n_act, bias, residual, ldr, gamma, beta, 0, stream);
+}
+
+extern "C" int scream_gemm_qkv_x3_ex_f32(const float* A, int64_t lda, const void* W_planes, float* Q, int64_t ldq, int64_t M,
+                                         int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
+                                         const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
+                                         float* kv_partial, int32_t layout, void* stream) {
+    SCREAM_REQUIRE(A && W_planes && kv_partial && tile_cloud && cloud_row0 && cloud_len, SCREAM_EINVAL);
+    SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K >= 64 && K % 64 == 0 && (K / 32 - 2) % 3 == 0, SCREAM_EUNSUPPORTED);  // K = 64 + 192 j
+    SCREAM_REQUIRE((n_q == 0 || n_q == XBN) && N == n_q + 2 * XBN && row_base >= 0 && row_base % SCREAM_ROW_TILE == 0,
+                   SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE(n_q == 0 || (Q && ldq >= n_q && ldq % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0), SCREAM_EINVAL);
+    SCREAM_REQUIRE(lda >= K && lda % 4 == 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W_planes) & 15) == 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE(!(layout & SCREAM_LAYOUT_C_FRAG) || n_q == XBN, SCREAM_EUNSUPPORTED);
+    if (int rc = check_layout(layout, lda, n_q ? ldq : SCREAM_D_MODEL, K, SCREAM_EPI_QKV, n_q ? n_q : SCREAM_D_MODEL)) return rc;
+    EpiArgs ep{n_q, nullptr, nullptr, 0, nullptr, nullptr, kv_partial, tile_cloud, cloud_row0, cloud_len, row_base,
+               (layout & SCREAM_LAYOUT_C_FRAG) ? 1 : 0};
+    return launch_x3<SCREAM_EPI_QKV>(A, lda, W_planes, Q, ldq, M, N, K, ep, as_stream(stream), layout & SCREAM_LAYOUT_A_FRAG);
 }
 
 extern "C" int scream_gemm_qkv_x3_f32(const float* A, int64_t lda, const void* W_planes, float* Q, int64_t ldq, int64_t M,
                                       int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
                                       const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
                                       float* kv_partial, void* stream) {
-    SCREAM_REQUIRE(A && W_planes && kv_partial && tile_cloud && cloud_row0 && cloud_len, SCREAM_EINVAL);
-    SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K >= 64 && K % 64 == 0 && (K / 32 - 2) % 3 == 0, SCREAM_EUNSUPPORTED);  // K = 64 + 192 j: an EVEN number of k-tiles (stage = kt & 1), in groups of three after the first two
-    SCREAM_REQUIRE((n_q == 0 || n_q == XBN) && N == n_q + 2 * XBN && row_base >= 0 && row_base % SCREAM_ROW_TILE == 0,
-                   SCREAM_EUNSUPPORTED);
-    SCREAM_REQUIRE(n_q == 0 || (Q && ldq >= n_q && ldq % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0), SCREAM_EINVAL);
-    SCREAM_REQUIRE(lda >= K && lda % 4 == 0, SCREAM_EINVAL);
-    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W_planes) & 15) == 0, SCREAM_EINVAL);
-    EpiArgs ep{n_q, nullptr, nullptr, 0, nullptr, nullptr, kv_partial, tile_cloud, cloud_row0, cloud_len, row_base};
-    return launch_x3<SCREAM_EPI_QKV>(A, lda, W_planes, Q, ldq, M, N, K, ep, as_stream(stream));
+    return scream_gemm_qkv_x3_ex_f32(A, lda, W_planes, Q, ldq, M, N, K, n_q, tile_cloud, cloud_row0, cloud_len, row_base, kv_partial,
+                                     0, stream);
 }

@@ -69,7 +69,13 @@ __device__ __forceinline__ void split3(const f32x4 lo, const f32x4 hi, bf16x8& p
 // this wave -- the DMA pieces of the stage after the one about to be read -- stay in flight across the barrier.
 template <int N>
 __device__ __forceinline__ void ring_barrier() {
-    __builtin_amdgcn_s_waitcnt(0x0070 | (N & 15) | ((N >> 4) << 14));
+    constexpr int W = (T_ABLATE & 1) ? 0 : N;  // the "no DMA" tuning build has no pieces to leave in flight: it must drain,
+    __builtin_amdgcn_s_waitcnt(0x0070 | (W & 15) | ((W >> 4) << 14));  // or row operands would still be pending at their use
+    __builtin_amdgcn_s_barrier();
+}
+
+__device__ __forceinline__ void lds_only_barrier() {  // lgkmcnt(0) + workgroup barrier, vector-memory queue untouched
+    __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
 }
 
@@ -329,6 +335,608 @@ __global__ void pack_ffn_kernel(const float* __restrict__ W1, const float* __res
     *reinterpret_cast<bf16x8*>(dst + 2 * 16 * 64 * 8) = p2;
 }
 
+
+// =================================================================================================================
+// The whole row-local tail of the block: attention apply (models/transformer.py:41-42), merge + norm1 (:83-84) and the
+// FFN + norm2 above, one launch.  Per 128-row tile the weight ring carries 72 stages: Wm head 0..7, then the 64 FFN
+// stages.  Merge stage h:  att_h^T = (KV_h^T . Q'_h^T) * Z * S  is a 32 x 32 x 32 product whose accumulator tile is,
+// again, exactly the B operand of  m^T += Wm[:, head h] . att_h^T;  the apply of head h + 1 (12 MFMAs, Z, split) rides
+// under the 96 MFMAs of head h.  LayerNorm1 turns the merge accumulators (+ x) into the bf16 planes of m1 in place.
+// Neither att nor m1 nor the hidden activations exist in memory: per row and layer the kernel reads Q' and x (twice)
+// and writes y -- 4 KB against the 15 KB of apply + merge + FFN-up + FFN-down.
+//
+// Row operands.  Lane (r, half) needs, of every 128-byte segment of row r, the 16-byte pieces 2a + half (the layout
+// convention above).  From a row-major matrix that is a row-per-lane access -- 32 to 64 distinct lines per wave
+// instruction, ~400 cycles of the CU's texture unit each, a quarter of the kernel however the requests were spread
+// (tools/tail_ablate.py, profiles/r02_tail_ablation_*.txt); staged through a wave-private LDS slab by LDS-DMA the lines
+// were full but, with room for one 4 KiB slab per wave, every request had half a stage of lead and the HBM latency showed
+// instead (+3 % only).  So the kernels agree on the layout in HBM: Q', x and y are FRAGMENT-major (SCREAM_ACT_FRAG,
+// include/scream_hip.h) -- per 32-row group and 32-feature segment the pieces are stored [a][lane], i.e. each of a lane's
+// four loads or stores per segment is one contiguous 1 KiB wave access that lands in exactly the registers the MFMA
+// wants, with no LDS in between.  All row operands are inline-asm register loads (hipcc would otherwise wait vmcnt(0)
+// at their first use and drain the weight ring), requested one stage ahead and BEFORE the stage's weight pieces so that
+// the ring's counted wait covers them as well.
+constexpr int TAIL_STAGES = 72;
+constexpr int KV_PLANES_BYTES = 8 * 3 * 2 * 1024;            // per cloud: [head][plane][step][lane][8] bf16
+constexpr int KV_IMAGE_BYTES = KV_PLANES_BYTES + 8 * 32 * 4;  // + Ksum [head][32] fp32
+
+__device__ __forceinline__ void ld_asm(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p)); }
+__device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+
+struct HeadOps {   // what the apply of one head needs, as loaded
+    f32x4 q[4];    // Q'[row, 32 h + 8 a + 4 half .. + 4], a = 0 .. 3
+    f32x4 kv[6];   // KV_h^T fragments [plane][step], 16 bytes per lane
+    f32x4 ks[4];   // Ksum[h][8 a + 4 half .. + 4]
+};
+
+// s_waitcnt vmcnt(N) alone, as an asm statement: ordered against the other asm statements (slab reads, register loads)
+#define VM_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define LGKM_WAIT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// acc += W . act, plain (no scheduling directives): for the short products that ride inside another stage's groups
+__device__ __forceinline__ void mfma6_free(f32x16& acc, const bf16x8 (&w)[3], const bf16x8 (&a)[3]) {
+    if (T_ABLATE & 2) {
+        acc[0] += (float)w[0][0] + (float)a[0][0];
+        return;
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], a[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], a[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], a[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[0], acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict__ Q,      // fragment-major [M, 256]
+                                                        const char* __restrict__ kvimg,   // [n_clouds][KV_IMAGE_BYTES]
+                                                        const int32_t* __restrict__ tile_cloud, int kv_cloud_offset,
+                                                        const int32_t* __restrict__ cloud_len,
+                                                        const float* __restrict__ xres,   // fragment-major [M, 256]
+                                                        const __bf16* __restrict__ Wimg,  // [72 stages][48 KiB]
+                                                        const float* __restrict__ g1, const float* __restrict__ b1,
+                                                        const float* __restrict__ g2, const float* __restrict__ b2,
+                                                        float* __restrict__ y,            // fragment-major [M, 256]
+                                                        int n_tiles) {
+    __shared__ __attribute__((aligned(16))) char smem[T_SLOTS * T_STAGE];  // 144 KiB, the ONLY LDS object
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const char* w_lane = reinterpret_cast<const char*>(Wimg) + lane * 16;
+    auto dma_piece = [&](unsigned q, int u) {
+        if ((T_ABLATE & 1) && q >= 2) return;
+        const unsigned src = q % (unsigned)TAIL_STAGES, slot = q % (unsigned)T_SLOTS;
+        const int piece = wave * 12 + u;
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_lane + (size_t)src * T_STAGE + piece * 1024),
+                                         (lptr_t)(smem + slot * T_STAGE + piece * 1024), 16, 0, 0);
+    };
+    unsigned q = 0;  // next stage to be consumed
+#pragma unroll
+    for (int u = 0; u < 12; ++u) dma_piece(0, u);
+#pragma unroll
+    for (int u = 0; u < 12; ++u) dma_piece(1, u);
+
+    // ---- row operand requests (inline asm; every consumer sits behind a counted wait + pin) -------------------------
+    // RULE (tools/asm_inflight_check.py enforces it on the generated code): a requested register is consumed at the top
+    // of the NEXT stage, never kept pending across a LayerNorm block -- hipcc, which believes the value present, otherwise
+    // spills it to scratch right behind the asm statement when registers are short there.
+    // grp: first float of the wave's 32-row group (8192 floats in either layout); segment seg, piece a, this lane:
+    auto frag_ptr = [&](const float* base, int64_t grp, int seg, int a) { return base + grp + ((seg * 4 + a) * 64 + lane) * 4; };
+    auto req_head = [&](HeadOps& o, int64_t grp, const char* kvc, int h) {
+        if (T_ABLATE & 16) return;
+        const char* kp = kvc + h * (3 * 2 * 1024) + lane * 16;
+        const float* sp = reinterpret_cast<const float*>(kvc + KV_PLANES_BYTES) + 32 * h + 4 * half;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) ld_asm(o.q[a], frag_ptr(Q, grp, h, a));
+#pragma unroll
+        for (int f = 0; f < 6; ++f) ld_asm(o.kv[f], kp + f * 1024);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) ld_asm(o.ks[a], sp + 8 * a);
+    };
+    auto req_x = [&](f32x4 (&xs)[4], int64_t grp, int blk) {
+        if (T_ABLATE & 16) return;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) ld_asm(xs[a], frag_ptr(xres, grp, blk, a));
+    };
+    auto pin_head = [&](HeadOps& o) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { pin(o.q[a]); pin(o.ks[a]); }
+#pragma unroll
+        for (int f = 0; f < 6; ++f) pin(o.kv[f]);
+    };
+    auto pin_x = [&](f32x4 (&xs)[4]) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) pin(xs[a]);
+    };
+    auto add_x = [&](f32x16& t, const f32x4 (&xs)[4]) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[4 * a + k] += (T_ABLATE & 16) ? 1.0f : xs[a][k];
+    };
+
+    HeadOps op;             // ONE operand buffer: a stage consumes it in its first groups and re-requests into it right after
+    f32x4 xs[4], xs2[4];    // x segments (xs2: only segment 7 of the norm1 residual)
+    bf16x8 apA[2][3], apB[2][3];  // planes of att_h^T, the B operand of the merge GEMM: heads of even / odd index
+    f32x16 aT;              // att_h^T tile of the head being applied
+    bf16x8 qp[2][3];
+    float Zs = 0.f;
+
+    // ---- apply of one head (models/transformer.py:41-42), in pieces that ride inside the groups of another stage ----
+    auto apply_qsplit = [&](int tile_tag) {
+        if (T_ABLATE & 16) {
+            const f32x4 f = {(float)lane, 1.0f, 0.5f, (float)tile_tag};
+            split3(f, f, qp[0][0], qp[0][1], qp[0][2]);
+            split3(f, f, qp[1][0], qp[1][1], qp[1][2]);
+            return;
+        }
+        split3(op.q[0], op.q[1], qp[0][0], qp[0][1], qp[0][2]);
+        split3(op.q[2], op.q[3], qp[1][0], qp[1][1], qp[1][2]);
+    };
+    auto apply_mfma = [&](int s2) {
+        bf16x8 w[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) w[p] = __builtin_bit_cast(bf16x8, op.kv[p * 2 + s2]);
+        if (s2 == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) aT[e] = 0.f;
+        }
+        mfma6_free(aT, w, qp[s2]);
+    };
+    auto apply_z = [&]() {  // Z = 1 / (Q'.Ksum + 1e-6); lanes r and r + 32 share row r
+        float zp = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) zp += op.q[a][k] * op.ks[a][k];
+        zp += __shfl_xor(zp, 32);
+        Zs = 1.0f / (zp + 1e-6f);
+    };
+    auto apply_split_pair = [&](int k, bf16x8 (&ap)[2][3], float S) {  // elements 2k, 2k+1: (aT * Z) * S, then the 3-way split
+        const int s2 = k >> 2, j = (2 * k) & 7;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float x = (aT[2 * k + e] * Zs) * S;
+            const __bf16 a = (__bf16)x;
+            const float r1 = x - (float)a;
+            const __bf16 b = (__bf16)r1;
+            ap[s2][0][j + e] = a;
+            ap[s2][1][j + e] = b;
+            ap[s2][2][j + e] = (__bf16)(r1 - (float)b);
+        }
+    };
+    // the pieces of one apply as they ride in group g of a 16-group stage: operands consumed in groups 0-3
+    auto apply_ride = [&](int g, bf16x8 (&ap)[2][3], float S, int tile_tag) {
+        if (g == 0) apply_qsplit(tile_tag);
+        if (g == 1) apply_mfma(0);
+        if (g == 2) apply_mfma(1);
+        if (g == 3) apply_z();
+        if (g >= 4 && g < 12) apply_split_pair(g - 4, ap, S);
+    };
+
+    int tile = blockIdx.x;
+    int64_t grp = ((int64_t)tile * 128 + wave * 32) * SCREAM_D_MODEL;  // first float of this wave's 32-row group
+    const char* kvc = nullptr;
+    float S = 1.f;
+    if (tile < n_tiles) {  // the block's first tile: heads 0 and 1 are applied in the open (once per block)
+        const int cl = tile_cloud[tile] + kv_cloud_offset;
+        kvc = kvimg + (size_t)cl * KV_IMAGE_BYTES;
+        S = (float)cloud_len[cl];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            req_head(op, grp, kvc, h);
+            VM_WAIT(0);
+            pin_head(op);
+#pragma unroll
+            for (int g = 0; g < 12; ++g) apply_ride(g, h == 0 ? apA : apB, S, tile);
+        }
+    }
+
+    while (tile < n_tiles) {
+        f32x16 acc[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+        // the block's next tile (its heads 0 and 1 are applied under / right after this tile's last stage)
+        const int tile_next = tile + (int)gridDim.x;
+        const bool has_next = tile_next < n_tiles;
+        const int64_t grp_next = ((int64_t)tile_next * 128 + wave * 32) * SCREAM_D_MODEL;
+        const char* kvc_next = kvc;
+        float S_next = 1.f;
+        if (has_next) {
+            const int cl = tile_cloud[tile_next] + kv_cloud_offset;
+            kvc_next = kvimg + (size_t)cl * KV_IMAGE_BYTES;
+            S_next = (float)cloud_len[cl];
+        }
+
+        // merge stage of head h: m^T += Wm[:, head h] . att_h^T with att_h's planes in `ap` (heads 0, 1: applied during the
+        // previous tile).
+        //   top:         x segment h - 1 (the norm1 residual, requested by stage h - 1) is added into accumulator tile h - 1,
+        //                then segment h is requested (stage 6 also requests segment 7, stage 7 adds both);
+        //   groups 0-3:  stages 1 .. 6 consume the operands of head h + 1 (requested by stage h - 1) -- its apply rides here;
+        //   group 4:     the operand buffer is re-requested for head h + 2 (stage 0: requested at the top);
+        //   groups 4-15: the stage's weight pieces, AFTER every row request, so that the next barrier's vmcnt(12) covers them.
+        auto stage_merge = [&](auto hh, bf16x8 (&ap)[2][3], bf16x8 (&ap_next)[2][3]) {
+            constexpr int h = decltype(hh)::value;
+            constexpr bool RIDE = h >= 1 && h <= 6;
+            // stage 0 of a tile: everything older was drained at the end of the previous tile (only its y stores may
+            // still be in flight, and nothing of this stage depends on them)
+            if (h == 0) lds_only_barrier(); else ring_barrier<12>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (h > 0) {
+                pin_x(xs);
+                add_x(acc[h > 0 ? h - 1 : 0], xs);
+                if (RIDE) pin_head(op);
+            }
+            if (h == 7) {
+                pin_x(xs2);
+                add_x(acc[7], xs2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (h < 7) req_x(xs, grp, h);
+            if (h == 6) req_x(xs2, grp, 7);
+            if (h == 0) req_head(op, grp, kvc, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            const char* wb = smem + (q % T_SLOTS) * T_STAGE + lane * 16;
+            bf16x8 wf[3][3];
+#pragma unroll
+            for (int g0 = 0; g0 < 2; ++g0)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wf[g0][p] = ld_frag(wb + (p * 16 + g0) * 1024);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {  // g = blk * 2 + s2
+                if (g + 2 < 16) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) wf[(g + 2) % 3][p] = ld_frag(wb + (p * 16 + g + 2) * 1024);
+                }
+                if (g == 4 && RIDE && h + 2 < 8) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    req_head(op, grp, kvc, h + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (g >= 4) dma_piece(q + 2, g - 4);
+                if (RIDE) apply_ride(g, ap_next, S, tile);
+                mfma6(acc[g >> 1], wf[g % 3], ap[g & 1]);
+            }
+            ++q;
+        };
+        constexpr std::integral_constant<bool, true> yes{};
+        constexpr std::integral_constant<bool, false> no{};
+#define HEAD(n) std::integral_constant<int, n>{}
+        //            head   planes  planes of head + 1
+        stage_merge(HEAD(0), apA, apB);
+        stage_merge(HEAD(1), apB, apA);
+        stage_merge(HEAD(2), apA, apB);
+        stage_merge(HEAD(3), apB, apA);
+        stage_merge(HEAD(4), apA, apB);
+        stage_merge(HEAD(5), apB, apA);
+        stage_merge(HEAD(6), apA, apB);
+        stage_merge(HEAD(7), apB, apA);
+
+        // ---- m1 = LayerNorm1(merge + x) (models/transformer.py:84), straight into the B-operand planes of FFN-up ---
+        bf16x8 mp[16][3];
+        {
+            float sum = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum += acc[b][e];
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / 256.0f);
+            float var = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    acc[b][e] -= mean;
+                    var += acc[b][e] * acc[b][e];
+                }
+            var += __shfl_xor(var, 32);
+            const float rstd = 1.0f / sqrtf(var * (1.0f / 256.0f) + 1e-5f);
+            const float* gp = g1 + 4 * half;
+            const float* bp = b1 + 4 * half;
+            asm volatile("" : "+v"(gp), "+v"(bp));  // not hoisted out of the tile loop (see ffn_x3_kernel)
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    f32x4 v[2];
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2) {
+                        const int a = 2 * s2 + a2;
+                        const f32x4 g4 = ld4(gp + 32 * b + 8 * a), b4 = ld4(bp + 32 * b + 8 * a);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[a2][k] = acc[b][4 * a + k] * rstd * g4[k] + b4[k];
+                    }
+                    split3(v[0], v[1], mp[2 * b + s2][0], mp[2 * b + s2][1], mp[2 * b + s2][2]);
+                }
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+        }
+
+        // ---- FFN (as ffn_x3_kernel); x segments 0 .. 7 (the norm2 residual) are added under the first eight down stages
+        f32x16 hT;
+        bf16x8 hpA[2][3], hpB[2][3];
+        auto split_pair = [&](int k, bf16x8 (&hout)[2][3]) {
+            const int s2 = k >> 2, j = (2 * k) & 7;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float x = fmaxf(hT[2 * k + e], 0.f);
+                const __bf16 a = (__bf16)x;
+                const float r1 = x - (float)a;
+                const __bf16 b = (__bf16)r1;
+                hout[s2][0][j + e] = a;
+                hout[s2][1][j + e] = b;
+                hout[s2][2][j + e] = (__bf16)(r1 - (float)b);
+            }
+        };
+        // XLOAD: x segment to request in this stage (-1: none)
+        auto stage_up = [&](auto first, auto xload) {
+            constexpr int XLOAD = decltype(xload)::value;
+            // FIRST: the norm1 block above used ordinary loads (gamma, beta), which hipcc waits for with vmcnt(0)
+            if (decltype(first)::value) ring_barrier<0>(); else ring_barrier<12>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (XLOAD >= 0) req_x(xs, grp, XLOAD);
+            __builtin_amdgcn_sched_barrier(0);
+            const char* wb = smem + (q % T_SLOTS) * T_STAGE + lane * 16;
+            bf16x8 wf[3][3];
+#pragma unroll
+            for (int g0 = 0; g0 < 2; ++g0)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wf[g0][p] = ld_frag(wb + (p * 16 + g0) * 1024);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) hT[e] = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                if (g + 2 < 16) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) wf[(g + 2) % 3][p] = ld_frag(wb + (p * 16 + g + 2) * 1024);
+                }
+                if (g < 12) dma_piece(q + 2, g);
+                mfma6(hT, wf[g % 3], mp[g]);
+            }
+            ++q;
+        };
+        // XADD: x segment (requested by the previous stage) to add into its accumulator tile (-1: none).
+        // RIDE (the tile's last two stages, when the FFN's operand planes are dead and registers are available again):
+        // 1 = requests the operands of the next tile's head 0; 2 = the apply of that head rides here, and head 1 is
+        // requested behind it (applied in the open right after the stage).
+        auto stage_down = [&](bf16x8 (&hin)[2][3], bf16x8 (&hout)[2][3], auto with_split, auto xadd, auto ride) {
+            constexpr int XADD = decltype(xadd)::value;
+            constexpr int RIDE = decltype(ride)::value;
+            ring_barrier<12>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (XADD >= 0) {
+                pin_x(xs);
+                add_x(acc[XADD >= 0 ? XADD : 0], xs);
+            }
+            if (RIDE == 2) pin_head(op);  // (untouched registers when the block has no next tile: the results are never used)
+            __builtin_amdgcn_sched_barrier(0);
+            if (RIDE == 1 && has_next) req_head(op, grp_next, kvc_next, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const char* wb = smem + (q % T_SLOTS) * T_STAGE + lane * 16;
+            bf16x8 wf[3][3];
+#pragma unroll
+            for (int g0 = 0; g0 < 2; ++g0)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wf[g0][p] = ld_frag(wb + (p * 16 + g0) * 1024);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {  // g = blk * 2 + s2
+                if (g + 2 < 16) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) wf[(g + 2) % 3][p] = ld_frag(wb + (p * 16 + g + 2) * 1024);
+                }
+                if (RIDE == 2 && g == 4) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has_next) req_head(op, grp_next, kvc_next, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (RIDE == 2) {
+                    if (g >= 4) dma_piece(q + 2, g - 4);
+                } else {
+                    if (g < 12) dma_piece(q + 2, g);
+                }
+                if (RIDE == 2) apply_ride(g, apA, S_next, tile_next);
+                if (decltype(with_split)::value && (g & 1) == 0) split_pair(g >> 1, hout);
+                mfma6(acc[g >> 1], wf[g % 3], hin[g & 1]);
+            }
+            ++q;
+        };
+        constexpr std::integral_constant<int, -1> none{};
+        constexpr std::integral_constant<int, 0> ride0{};
+        // stage order (= image order): W1_0 | W1_c, W2_{c-1} for c = 1 .. 31 | W2_31.  The norm2 residual: the up stage of
+        // chunk c requests x segment c - 1, the down stage of chunk c - 1 that follows adds it (c - 1 < 8) -- the first
+        // four pair iterations are peeled so that every accumulator index is a compile-time constant.
+        stage_up(yes, none);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) split_pair(k, hpA);
+#define PAIR(c)                                                                             \
+        stage_up(no, HEAD((c) - 1));                          /* chunk c */                  \
+        stage_down(hpA, hpB, yes, HEAD((c) - 1), ride0);      /* chunk c - 1, splits c */     \
+        stage_up(no, HEAD(c));                                /* chunk c + 1 */              \
+        stage_down(hpB, hpA, yes, HEAD(c), ride0);            /* chunk c, splits c + 1 */
+        PAIR(1) PAIR(3) PAIR(5) PAIR(7)
+#undef PAIR
+        for (int c = 9; c < 31; c += 2) {
+            stage_up(no, none);
+            stage_down(hpA, hpB, yes, none, ride0);
+            stage_up(no, none);
+            stage_down(hpB, hpA, yes, none, ride0);
+        }
+        stage_up(no, none);                           // chunk 31
+        stage_down(hpA, hpB, yes, none, HEAD(1));      // chunk 30, splitting chunk 31; requests head 0 of the block's next tile
+        stage_down(hpB, hpA, no, none, HEAD(2));       // chunk 31; applies that head, requests head 1
+#undef HEAD
+        // Drain: the ring's two stages in flight and head 1 of the next tile, requested two thirds of a stage ago.  That
+        // head is applied here in the open (12 MFMAs), so that nothing pending lives across the norm2 block, and the y
+        // stores below are YOUNGER than every load a later counted wait is meant to cover (stores retire out of order with
+        // respect to loads, gemm_x3.hip; stage 0 of the next tile starts without a vector-memory wait).
+        VM_WAIT(0);
+        if (has_next) {
+            pin_head(op);
+#pragma unroll
+            for (int g = 0; g < 12; ++g) apply_ride(g, apB, S_next, tile_next);
+        }
+
+        // ---- y = LayerNorm2(x + ffn) (the residual is already in the accumulators), stored fragment-major ------------
+        {
+            float sum = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum += acc[b][e];
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / 256.0f);
+            float var = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    acc[b][e] -= mean;
+                    var += acc[b][e] * acc[b][e];
+                }
+            var += __shfl_xor(var, 32);
+            const float rstd = 1.0f / sqrtf(var * (1.0f / 256.0f) + 1e-5f);
+            const float* gp = g2 + 4 * half;
+            const float* bp = b2 + 4 * half;
+            asm volatile("" : "+v"(gp), "+v"(bp));
+            float* yg = y + grp + lane * 4;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const f32x4 g4 = ld4(gp + 32 * b + 8 * a), b4 = ld4(bp + 32 * b + 8 * a);
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = acc[b][4 * a + k] * rstd * g4[k] + b4[k];
+                    // one contiguous 1 KiB per wave instruction
+                    if (!(T_ABLATE & 16) || o[0] + o[1] + o[2] + o[3] == 123.456f) *reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256) = o;
+                }
+        }
+        tile = tile_next;
+        grp = grp_next;
+        kvc = kvc_next;
+        S = S_next;
+    }
+    VM_WAIT(0);  // the two stages requested past the end must have landed before the LDS is released
+}
+
+// [M, 256] fp32 row-major <-> fragment-major (SCREAM_ACT_FRAG, include/scream_hip.h).  One block per 32-row group: the
+// group is read in full lines, turned around in LDS and written in full lines.  Boundary use only (after the embedding,
+// for tests and for callers that hold row-major data).
+__global__ __launch_bounds__(256) void act_layout_kernel(const float* __restrict__ src, float* __restrict__ dst, int to_frag) {
+    __shared__ float tile[32][260];  // +4: the transposing accesses below touch rows 1040 bytes apart
+    const int t = threadIdx.x;
+    const float* s = src + (int64_t)blockIdx.x * 8192;
+    float* d = dst + (int64_t)blockIdx.x * 8192;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = t + 256 * i;  // float4 index inside the group
+        const f32x4 v = *reinterpret_cast<const f32x4*>(s + e * 4);
+        int row, col;
+        if (to_frag) {
+            row = e >> 6, col = (e & 63) * 4;  // source is row-major
+        } else {
+            const int ln = e & 63, a = (e >> 6) & 3, blk = e >> 8;  // source is fragment-major
+            row = ln & 31, col = 32 * blk + 8 * a + 4 * (ln >> 5);
+        }
+        *reinterpret_cast<f32x4*>(&tile[row][col]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = t + 256 * i;
+        int row, col;
+        if (to_frag) {
+            const int ln = e & 63, a = (e >> 6) & 3, blk = e >> 8;
+            row = ln & 31, col = 32 * blk + 8 * a + 4 * (ln >> 5);
+        } else {
+            row = e >> 6, col = (e & 63) * 4;
+        }
+        *reinterpret_cast<f32x4*>(d + e * 4) = *reinterpret_cast<const f32x4*>(&tile[row][col]);
+    }
+}
+
+// Wm [256][256], W1 [1024][256], W2 [256][1024] fp32 -> the 72 stage images of tail_x3_kernel: merge head h (stage h) is
+// "W2 chunk h" of a 256-deep matrix, stages 8 .. 71 are the FFN image.
+__global__ void pack_tail_kernel(const float* __restrict__ Wm, const float* __restrict__ W1, const float* __restrict__ W2,
+                                 __bf16* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= TAIL_STAGES * 16 * 64) return;
+    const int lane = t & 63, frag = (t >> 6) & 15, stage = t >> 10;
+    const int m = lane & 31, half = lane >> 5;
+    float v[8];
+    if (stage < 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Wm[(int64_t)(32 * (frag >> 1) + m) * 256 + 32 * stage + chunk_k(frag & 1, half, j)];
+    } else {
+        const int st = stage - 8;
+        const bool up = st == 0 || (st < 63 && (st & 1));
+        const int c = st == 0 ? 0 : st == 63 ? 31 : up ? (st + 1) / 2 : st / 2 - 1;
+        if (up) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = W1[(int64_t)(32 * c + m) * 256 + 32 * (frag >> 1) + chunk_k(frag & 1, half, j)];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = W2[(int64_t)(32 * (frag >> 1) + m) * 1024 + 32 * c + chunk_k(frag & 1, half, j)];
+        }
+    }
+    bf16x8 p0, p1, p2;
+    const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+    split3(lo, hi, p0, p1, p2);
+    __bf16* dst = out + ((int64_t)stage * 3 * 16 + frag) * 64 * 8 + lane * 8;
+    *reinterpret_cast<bf16x8*>(dst) = p0;
+    *reinterpret_cast<bf16x8*>(dst + 16 * 64 * 8) = p1;
+    *reinterpret_cast<bf16x8*>(dst + 2 * 16 * 64 * 8) = p2;
+}
+
+// Sum of the per-128-row-tile K^T V partials of the fused q/k/v GEMM (as kv_finalize_tiles_kernel, attention.hip) written
+// as the operand image of tail_x3_kernel: per cloud and head the A-operand fragments of KV_h^T / S (row m = value index
+// v, contraction index d = chunk_k(step, half, j)) in three bf16 planes, then Ksum as fp32.  grid n_kv * 8, block 1024.
+__global__ __launch_bounds__(1024) void kv_finalize_x3_kernel(const float* __restrict__ partial,
+                                                            const int32_t* __restrict__ cloud_row0,
+                                                            const int32_t* __restrict__ cloud_len, int64_t row_base,
+                                                            int cloud_begin, char* __restrict__ kvimg) {
+    constexpr int KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;
+    const int kvi = blockIdx.x / SCREAM_NHEAD, h = blockIdx.x % SCREAM_NHEAD;
+    const int cloud = cloud_begin + kvi;
+    const int t0 = (int)((cloud_row0[cloud] - row_base) / SCREAM_ROW_TILE);
+    const int nt = (cloud_len[cloud] + SCREAM_ROW_TILE - 1) / SCREAM_ROW_TILE;
+    const float* p = partial + ((int64_t)t0 * SCREAM_NHEAD + h) * KV_ELEMS;
+    char* img = kvimg + (size_t)cloud * KV_IMAGE_BYTES;
+    const float S = (float)cloud_len[cloud];
+    for (int i = threadIdx.x; i < KV_ELEMS; i += 1024) {
+        float s8[16];  // sixteen chains in a fixed combination order: deterministic (same order as kv_finalize_tiles_kernel)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s8[u] = 0.f;
+        for (int c = 0; c < nt; c += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (c + u < nt) s8[u] += p[(int64_t)(c + u) * SCREAM_NHEAD * KV_ELEMS + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += s8[u + 8];
+        const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        if (i < 32 * 32) {
+            const int d = i >> 5, v = i & 31;             // partial layout [d][v]
+            const float x = s / S;                         // values / v_length (models/transformer.py:38-39), applied to the sum
+            const int s2 = d >> 4, hf = (d >> 2) & 1, j = 4 * ((d >> 3) & 1) + (d & 3);  // d = chunk_k(s2, hf, j)
+            const __bf16 a = (__bf16)x;
+            const float r1 = x - (float)a;
+            const __bf16 b = (__bf16)r1;
+            const __bf16 cc = (__bf16)(r1 - (float)b);
+            __bf16* base = reinterpret_cast<__bf16*>(img) + ((size_t)(h * 3) * 2 + s2) * 512 + (v + 32 * hf) * 8 + j;
+            base[0] = a;
+            base[2 * 512] = b;
+            base[4 * 512] = cc;
+        } else {
+            reinterpret_cast<float*>(img + KV_PLANES_BYTES)[h * 32 + (i - 32 * 32)] = s;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t scream_ffn_image_bytes(void) { return (int64_t)FFN_STAGES * T_STAGE; }
@@ -354,6 +962,61 @@ extern "C" int scream_ffn_x3_f32(const float* m1, int64_t ldm, const void* ffn_i
     const unsigned grid = tiles < T_MAX_GRID ? (unsigned)tiles : (unsigned)T_MAX_GRID;
     ffn_x3_kernel<<<dim3(grid), dim3(TT), 0, as_stream(stream)>>>(m1, ldm, reinterpret_cast<const __bf16*>(ffn_image), residual, ldr, gamma,
                                                                  beta, y, ldy, (int)tiles);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t scream_tail_image_bytes(void) { return (int64_t)TAIL_STAGES * T_STAGE; }
+extern "C" int64_t scream_kv_image_bytes(void) { return KV_IMAGE_BYTES; }
+
+extern "C" int scream_pack_tail_x3(const float* Wm, const float* W1, const float* W2, void* image, void* stream) {
+    SCREAM_REQUIRE(Wm && W1 && W2 && image, SCREAM_EINVAL);
+    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, SCREAM_EINVAL);
+    pack_tail_kernel<<<dim3(TAIL_STAGES * 16 * 64 / 256), dim3(256), 0, as_stream(stream)>>>(Wm, W1, W2, reinterpret_cast<__bf16*>(image));
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int scream_kv_finalize_x3(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
+                                     int64_t row_base, int32_t cloud_begin, int32_t n_kv, void* kv_image, void* stream) {
+    SCREAM_REQUIRE(kv_partial && cloud_row0 && cloud_len && kv_image, SCREAM_EINVAL);
+    SCREAM_REQUIRE(n_kv >= 0 && cloud_begin >= 0 && row_base >= 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(kv_image) & 15) == 0, SCREAM_EINVAL);
+    if (n_kv == 0) return 0;
+    kv_finalize_x3_kernel<<<dim3(n_kv * SCREAM_NHEAD), dim3(1024), 0, as_stream(stream)>>>(kv_partial, cloud_row0, cloud_len, row_base,
+                                                                                         cloud_begin, reinterpret_cast<char*>(kv_image));
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int scream_layer_tail_x3_f32(const float* Q, const void* kv_image, const int32_t* tile_cloud,
+                                        int32_t kv_cloud_offset, const int32_t* cloud_len, const float* x,
+                                        const void* tail_image, const float* g1, const float* b1, const float* g2,
+                                        const float* b2, float* y, int64_t M, void* stream) {
+    SCREAM_REQUIRE(Q && kv_image && tile_cloud && cloud_len && x && tail_image && g1 && b1 && g2 && b2 && y, SCREAM_EINVAL);
+    SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE(((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(kv_image) | reinterpret_cast<uintptr_t>(x) |
+                     reinterpret_cast<uintptr_t>(tail_image) | reinterpret_cast<uintptr_t>(g1) | reinterpret_cast<uintptr_t>(b1) |
+                     reinterpret_cast<uintptr_t>(g2) | reinterpret_cast<uintptr_t>(b2) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE(x != y, SCREAM_EINVAL);  // the residual of a row is read twice, long after its neighbours were written
+    const int64_t tiles = M / SCREAM_ROW_TILE;
+    if (tiles == 0) return 0;
+    SCREAM_REQUIRE(tiles < (1ll << 31), SCREAM_EUNSUPPORTED);
+    const unsigned grid = tiles < T_MAX_GRID ? (unsigned)tiles : (unsigned)T_MAX_GRID;
+    tail_x3_kernel<<<dim3(grid), dim3(TT), 0, as_stream(stream)>>>(Q, reinterpret_cast<const char*>(kv_image), tile_cloud,
+                                                                  kv_cloud_offset, cloud_len, x,
+                                                                  reinterpret_cast<const __bf16*>(tail_image), g1, b1, g2, b2, y,
+                                                                  (int)tiles);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int scream_act_layout(const float* src, float* dst, int64_t M, int32_t to_fragment, void* stream) {
+    SCREAM_REQUIRE(src && dst && src != dst, SCREAM_EINVAL);
+    SCREAM_REQUIRE(M >= 0 && M % 32 == 0 && M / 32 < (1ll << 31), SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0, SCREAM_EINVAL);
+    if (M == 0) return 0;
+    act_layout_kernel<<<dim3((unsigned)(M / 32)), dim3(256), 0, as_stream(stream)>>>(src, dst, to_fragment ? 1 : 0);
     SCREAM_LAUNCH_CHECK();
     return 0;
 }

@@ -96,9 +96,12 @@ class PointTransformer(nn.Module):
     # x3 only: run FFN-up + relu + FFN-down + residual + LayerNorm2 as one launch (csrc/tail_x3.hip); SCREAM_FUSED_FFN=0
     # keeps the two GEMM launches (same arithmetic, the hidden activations then go through HBM)
     fused_ffn = os.environ.get("SCREAM_FUSED_FFN", "1") != "0"
+    # x3 only: attention apply, merge + LayerNorm1 and the FFN + LayerNorm2 as one launch per block; SCREAM_FUSED_TAIL=0
+    # falls back to attn_apply + merge GEMM + (fused or two-launch) FFN
+    fused_tail = os.environ.get("SCREAM_FUSED_TAIL", "1") != "0"
 
     def _signature(self):
-        return (self.gemm_backend, self.fused_ffn) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.gemm_backend, self.fused_ffn, self.fused_tail) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _pack_weights(self):
         sig = self._signature()
@@ -138,8 +141,16 @@ class PointTransformer(nn.Module):
             L.wqkv = dev_mat(torch.cat([m.q_proj.weight, wkv], dim=0))
             L.wq = dev_mat(m.q_proj.weight)
             L.wkv = dev_mat(wkv)
+            L.tail = None
+            if planes and self.fused_tail:  # one launch for everything behind the projections (scream_layer_tail_x3_f32)
+                f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32)
+                img = ops.pack_tail(f32(m.merge.weight), f32(m.mlp[0].weight), f32(m.mlp[2].weight))
+                keep.append(img)
+                L.tail = img.data_ptr()
             L.wm = dev_mat(m.merge.weight)
-            if planes and self.fused_ffn:  # one launch for the FFN half (scream_ffn_x3_f32); w1 / w2 are then unused
+            if L.tail is not None:
+                L.ffn, L.w1, L.w2 = None, None, None
+            elif planes and self.fused_ffn:  # one launch for the FFN half (scream_ffn_x3_f32); w1 / w2 are then unused
                 img = ops.pack_ffn(m.mlp[0].weight.detach().to(device=dev, dtype=torch.float32),
                                    m.mlp[2].weight.detach().to(device=dev, dtype=torch.float32))
                 keep.append(img)

@@ -62,19 +62,33 @@ def split_planes(W: torch.Tensor) -> torch.Tensor:
     return out
 
 
+LAYOUT_A_FRAG, LAYOUT_C_FRAG = 1, 2
+
+
+def act_layout(X: torch.Tensor, to_fragment: bool) -> torch.Tensor:
+    """[M,256] fp32 row-major <-> fragment-major (SCREAM_ACT_FRAG, include/scream_hip.h); returns a new tensor."""
+    M = X.shape[0]
+    assert X.shape[1] == D_MODEL
+    out = torch.empty_like(X)
+    check(_lib.load().scream_act_layout(_p(X), _p(out), M, int(to_fragment), _stream()), "scream_act_layout")
+    return out
+
+
 def gemm_x3(A: torch.Tensor, Wp: torch.Tensor, epilogue: int = EPI_NONE, n_act: int = 0,
             bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
             gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
-            out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """gemm_f32's contract on the bf16 matrix cores (3-way split, fp32-level accuracy); Wp = split_planes(W)."""
+            out: Optional[torch.Tensor] = None, layout: int = 0) -> torch.Tensor:
+    """gemm_f32's contract on the bf16 matrix cores (3-way split, fp32-level accuracy); Wp = split_planes(W).
+    layout: LAYOUT_A_FRAG (A is fragment-major) | LAYOUT_C_FRAG (the activated query tile is written fragment-major)."""
     M, K = A.shape
     N = Wp.shape[2]
     assert Wp.shape == (3, K // 32, N, 32) and Wp.dtype == torch.bfloat16
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32)
-    check(_lib.load().scream_gemm_x3_f32(_p(A), A.stride(0), _p(Wp, torch.bfloat16), _p(out), out.stride(0), M, N, K,
-                                         epilogue, n_act, _p(bias), _p(residual),
-                                         residual.stride(0) if residual is not None else 0, _p(gamma), _p(beta), _stream()),
+    check(_lib.load().scream_gemm_x3_ex_f32(_p(A), A.stride(0), _p(Wp, torch.bfloat16), _p(out), out.stride(0), M, N, K,
+                                            epilogue, n_act, _p(bias), _p(residual),
+                                            residual.stride(0) if residual is not None else 0, _p(gamma), _p(beta), layout,
+                                            _stream()),
           "scream_gemm_x3_f32")
     return out
 
@@ -101,8 +115,45 @@ def ffn_x3(m1: torch.Tensor, image: torch.Tensor, residual: torch.Tensor, gamma:
     return out
 
 
-def gemm_qkv(A: torch.Tensor, W: torch.Tensor, n_q: int, tile_cloud, cloud_row0, cloud_len, row_base: int):
-    """Fused q/k/v projection (scream_gemm_qkv_f32).  Returns (Q' [M,256] or None, kv_partial [M/128,8,1056])."""
+def pack_tail(Wm: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor) -> torch.Tensor:
+    """merge.weight [256,256], mlp.0.weight [1024,256], mlp.2.weight [256,1024] -> the weight image of layer_tail."""
+    Wm, W1, W2 = (w.detach().to(torch.float32).contiguous() for w in (Wm, W1, W2))
+    assert Wm.shape == (D_MODEL, D_MODEL) and W1.shape == (4 * D_MODEL, D_MODEL) and W2.shape == (D_MODEL, 4 * D_MODEL)
+    lib = _lib.load()
+    out = torch.empty(lib.scream_tail_image_bytes(), device=Wm.device, dtype=torch.uint8)
+    check(lib.scream_pack_tail_x3(_p(Wm), _p(W1), _p(W2), _p(out, torch.uint8), _stream()), "scream_pack_tail_x3")
+    return out
+
+
+def kv_finalize_x3(partial: torch.Tensor, cloud_row0, cloud_len, row_base: int, cloud_begin: int, n_kv: int,
+                   n_clouds: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K^T V partials of gemm_qkv -> the per-cloud operand image of layer_tail ([n_clouds, kv_image_bytes] uint8)."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.zeros(n_clouds, lib.scream_kv_image_bytes(), device=partial.device, dtype=torch.uint8)
+    check(lib.scream_kv_finalize_x3(_p(partial), _p(cloud_row0, torch.int32), _p(cloud_len, torch.int32), row_base,
+                                    cloud_begin, n_kv, _p(out, torch.uint8), _stream()), "scream_kv_finalize_x3")
+    return out
+
+
+def layer_tail(Q: torch.Tensor, kv_image: torch.Tensor, tile_cloud, kv_cloud_offset: int, cloud_len, x: torch.Tensor,
+               tail_image: torch.Tensor, g1, b1, g2, b2, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Attention apply + merge + norm1 + FFN + norm2 of one block in one launch (scream_layer_tail_x3_f32).
+    Q, x and the result are FRAGMENT-major [M,256] matrices (act_layout converts)."""
+    M = Q.shape[0]
+    assert Q.shape[1] == D_MODEL and x.shape == Q.shape
+    if out is None:
+        out = torch.empty(M, D_MODEL, device=Q.device, dtype=torch.float32)
+    check(_lib.load().scream_layer_tail_x3_f32(_p(Q), _p(kv_image, torch.uint8), _p(tile_cloud, torch.int32),
+                                               kv_cloud_offset, _p(cloud_len, torch.int32), _p(x),
+                                               _p(tail_image, torch.uint8), _p(g1), _p(b1), _p(g2), _p(b2), _p(out),
+                                               M, _stream()), "scream_layer_tail_x3_f32")
+    return out
+
+
+def gemm_qkv(A: torch.Tensor, W: torch.Tensor, n_q: int, tile_cloud, cloud_row0, cloud_len, row_base: int, layout: int = 0):
+    """Fused q/k/v projection (scream_gemm_qkv_f32).  Returns (Q' [M,256] or None, kv_partial [M/128,8,1056]).
+    layout (split kernel only): LAYOUT_A_FRAG | LAYOUT_C_FRAG."""
     M, K = A.shape
     N = W.shape[0]
     x3 = W.dim() == 4  # packed bf16 planes (split_planes) -> the split kernel
@@ -110,10 +161,13 @@ def gemm_qkv(A: torch.Tensor, W: torch.Tensor, n_q: int, tile_cloud, cloud_row0,
         N = W.shape[2]
     Q = torch.empty(M, n_q, device=A.device, dtype=torch.float32) if n_q else None
     part = torch.empty(M // ROW_TILE, 8, KV_ELEMS, device=A.device, dtype=torch.float32)
-    fn = _lib.load().scream_gemm_qkv_x3_f32 if x3 else _lib.load().scream_gemm_qkv_f32
-    check(fn(_p(A), A.stride(0), _p(W, torch.bfloat16 if x3 else torch.float32), _p(Q), n_q, M, N, K, n_q,
-             _p(tile_cloud, torch.int32), _p(cloud_row0, torch.int32), _p(cloud_len, torch.int32), row_base, _p(part),
-             _stream()), "scream_gemm_qkv")
+    args = (_p(A), A.stride(0), _p(W, torch.bfloat16 if x3 else torch.float32), _p(Q), n_q, M, N, K, n_q,
+            _p(tile_cloud, torch.int32), _p(cloud_row0, torch.int32), _p(cloud_len, torch.int32), row_base, _p(part))
+    if x3:
+        check(_lib.load().scream_gemm_qkv_x3_ex_f32(*args, layout, _stream()), "scream_gemm_qkv_x3")
+    else:
+        assert layout == 0
+        check(_lib.load().scream_gemm_qkv_f32(*args, _stream()), "scream_gemm_qkv")
     return Q, part
 
 

@@ -64,7 +64,9 @@ def test_gemm_plain_and_activations(M, N, K, kind):
 
 def test_pack_w_x3_is_an_exact_split():
     """scream_pack_w_x3: the three bf16 planes sum back to W bit for bit (in fp32 and in fp64), and the image is the
-    documented k-tile-major layout with the 16-byte chunk swizzle (include/scream_hip.h)."""
+    documented k-tile-major layout: logical chunk c = 2 half + s of a 32-deep k-slice holds the contraction indices
+    8 (2 s + (j >> 2)) + 4 half + (j & 3), j = 0 .. 7 (what lane-half `half` supplies in step s), stored at chunk
+    c ^ ((n >> 2) & 3) (gemm_x3.hip)."""
     g = torch.Generator().manual_seed(3)
     N, K = 512, 160
     W = torch.randn(N, K, generator=g) * torch.logspace(-6, 3, N).unsqueeze(1)  # nine decades of magnitudes
@@ -79,7 +81,12 @@ def test_pack_w_x3_is_an_exact_split():
             c = chunk[:, cs]
             for cc in range(4):
                 sel = c == cc
-                planes[:, sel, kt * 32 + cc * 8: kt * 32 + cc * 8 + 8] = rows[:, sel, cs]
+                hf, st = cc >> 1, cc & 1
+                ks = [kt * 32 + 8 * (2 * st + (j >> 2)) + 4 * hf + (j & 3) for j in range(8)]
+                planes[:, sel][:, :, ks] = rows[:, sel, cs]
+                tmp = planes[:, sel]
+                tmp[:, :, ks] = rows[:, sel, cs]
+                planes[:, sel] = tmp
     assert torch.equal((planes[0] + planes[1]) + planes[2], W)
     assert torch.equal(planes.double().sum(0), W.double())
     assert torch.equal(planes[0], W.to(torch.bfloat16).float())
@@ -587,3 +594,90 @@ def test_fused_ffn_identity_weights_expose_the_permutation():
     out = ops.ffn_x3(dev(m1), ops.pack_ffn(dev(W1), dev(W2)), dev(x), dev(g), dev(b)).cpu()
     want = _ffn_reference(m1, W1, W2, x, g, b)
     torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------- fused layer tail (tail_x3.hip)
+@pytest.mark.parametrize("cross", [False, True])
+def test_fused_layer_tail_vs_oracle_block(cross):
+    """One whole MHAttention block (models/transformer.py:74-90) on the fused path: q/k/v projection GEMM (K^T V in its
+    epilogue) -> scream_kv_finalize_x3 -> scream_layer_tail_x3_f32 (apply, merge + norm1, FFN + norm2 in ONE launch; att,
+    m1 and the hidden activations never reach memory) against the oracle block, on ragged clouds with padding rows, for
+    a self block (three clouds, several row tiles per block) and a cross block (queries and keys from different clouds)."""
+    sd = make_state_dict(21, 256, 1, 1)
+    pre = "cross.1.layer." if cross else "stem.0."
+    rng = np.random.default_rng(5)
+    lens = [300, 129, 700]
+    row0 = [0, 384, 640]
+    rows = 640 + 768
+    x = torch.zeros(rows, 256)
+    xs = [torch.from_numpy(rng.normal(size=(n, 256)).astype(np.float32)) for n in lens]
+    for r0, xc in zip(row0, xs):
+        x[r0:r0 + xc.shape[0]] = xc
+    x[300:384] = 3.0  # garbage in padding rows must not reach the K^T V reduction
+    tiles = torch.tensor([0] * 3 + [1] * 2 + [2] * 6, dtype=torch.int32)
+    crow0, clen = dev(torch.tensor(row0, dtype=torch.int32)), dev(torch.tensor(lens, dtype=torch.int32))
+    q, k, v = (sd[pre + "%s_proj.weight" % n] for n in "qkv")
+    Wkv = torch.cat([k[:128], v[:128], k[128:], v[128:]], dim=0)
+    img = ops.pack_tail(dev(sd[pre + "merge.weight"]), dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"]))
+    g1, b1, g2, b2 = (dev(sd[pre + n]) for n in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"))
+    xd = dev(x)
+    xf = ops.act_layout(xd, True)  # the fused path passes activations FRAGMENT-major between its kernels
+    FR = ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG
+    assert torch.equal(ops.act_layout(xf, False), xd)
+    if not cross:
+        Q, part = ops.gemm_qkv(xf, ops.split_planes(dev(torch.cat([q, Wkv], dim=0))), 256, dev(tiles), crow0, clen, 0, FR)
+        Qr, part_r = ops.gemm_qkv(xd, ops.split_planes(dev(torch.cat([q, Wkv], dim=0))), 256, dev(tiles), crow0, clen, 0)
+        assert torch.equal(ops.act_layout(Q, False), Qr) and torch.equal(part, part_r)  # same numbers, two layouts
+        kvi = ops.kv_finalize_x3(part, crow0, clen, 0, 0, 3, 3)
+        y = ops.act_layout(ops.layer_tail(Q, kvi, dev(tiles), 0, clen, xf, img, g1, b1, g2, b2), False).cpu()
+        for r0, xc in zip(row0, xs):
+            want = O.mh_attention(xc[None], xc[None], xc[None], sd, pre)[0]
+            torch.testing.assert_close(y[r0:r0 + xc.shape[0]], want, rtol=2e-4, atol=5e-5)
+    else:
+        # queries: cloud 0 (rows 0..383); keys/values: cloud 2 (rows 640..) -- "source attends to target", kv_cloud_offset 2
+        Q = ops.gemm_x3(xf[:384], ops.split_planes(dev(q)), ops.EPI_ELU1, n_act=256, layout=FR)
+        _, part = ops.gemm_qkv(xf[640:], ops.split_planes(dev(Wkv)), 0, dev(tiles), crow0, clen, 640, ops.LAYOUT_A_FRAG)
+        kvi = ops.kv_finalize_x3(part, crow0, clen, 640, 2, 1, 3)
+        y = ops.act_layout(ops.layer_tail(Q, kvi, dev(tiles[:3].contiguous()), 2, clen, xf[:384], img, g1, b1, g2, b2), False).cpu()
+        want = O.mh_attention(xs[0][None], xs[2][None], xs[2][None], sd, pre)[0]
+        torch.testing.assert_close(y[:300], want, rtol=2e-4, atol=5e-5)
+    assert torch.isfinite(y).all()
+
+
+def test_fused_layer_tail_many_tiles_equals_unfused_path():
+    """33 024 rows = 258 row tiles on 256 persistent blocks (some blocks walk two tiles: the next tile's first two heads
+    are applied under the current tile's last stages) in 40 ragged clouds: the fused tail against the kernels it
+    replaces (attn_apply + merge GEMM + fused FFN), same split-bf16 arithmetic, different summation order."""
+    g_ = torch.Generator().manual_seed(3)
+    n_clouds, rows = 40, 33024
+    bounds = torch.linspace(0, rows // 128, n_clouds + 1).round().int()
+    lens, row0, tiles = [], [], []
+    for c in range(n_clouds):
+        t0, t1 = int(bounds[c]), int(bounds[c + 1])
+        row0.append(t0 * 128)
+        lens.append((t1 - t0) * 128 - int(torch.randint(0, 127, (1,), generator=g_)))
+        tiles += [c] * (t1 - t0)
+    x = torch.randn(rows, 256, generator=g_)
+    sd = make_state_dict(4, 256, 1, 1)
+    pre = "stem.0."
+    q, k, v = (sd[pre + "%s_proj.weight" % n] for n in "qkv")
+    W = torch.cat([q, k[:128], v[:128], k[128:], v[128:]], dim=0)
+    tc, crow0, clen = dev(torch.tensor(tiles, dtype=torch.int32)), dev(torch.tensor(row0, dtype=torch.int32)), dev(torch.tensor(lens, dtype=torch.int32))
+    g1, b1, g2, b2 = (dev(sd[pre + n]) for n in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"))
+    xd = dev(x)
+    xf = ops.act_layout(xd, True)
+    Qf, part = ops.gemm_qkv(xf, ops.split_planes(dev(W)), 256, tc, crow0, clen, 0, ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG)
+    Q = ops.act_layout(Qf, False)
+    img = ops.pack_tail(dev(sd[pre + "merge.weight"]), dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"]))
+    kvi = ops.kv_finalize_x3(part, crow0, clen, 0, 0, n_clouds, n_clouds)
+    yf = ops.layer_tail(Qf, kvi, tc, 0, clen, xf, img, g1, b1, g2, b2)
+    y = ops.act_layout(yf, False)
+    kv = ops.kv_finalize(part, crow0, clen, 0, 0, n_clouds, n_clouds)
+    att = ops.attn_apply(Q, 256, kv, tc, 0, clen, rows)
+    m1 = ops.gemm_x3(att, ops.split_planes(dev(sd[pre + "merge.weight"])), ops.EPI_RES_LN, residual=xd, gamma=g1, beta=b1)
+    want = ops.ffn_x3(m1, ops.pack_ffn(dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"])), xd, g2, b2)
+    valid = torch.zeros(rows, dtype=torch.bool)
+    for r0, n in zip(row0, lens):
+        valid[r0:r0 + n] = True
+    torch.testing.assert_close(y.cpu()[valid], want.cpu()[valid], rtol=1e-4, atol=2e-5)
+    assert torch.equal(ops.layer_tail(Qf, kvi, tc, 0, clen, xf, img, g1, b1, g2, b2), yf)  # deterministic

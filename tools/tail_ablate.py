@@ -16,7 +16,7 @@ def build():
     os.makedirs(OUT, exist_ok=True)
     procs = []
     for bits, _ in VARIANTS:
-        cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-DT_ABLATE=%d" % bits, *EXTRA,
+        cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-DT_ABLATE=%d" % bits, *EXTRA,
                os.path.join(ROOT, os.environ.get("T_SRC", "scream_amd/csrc/tail_x3.hip")), "-o", os.path.join(OUT, "t_%d.so" % bits)]
         procs.append(subprocess.Popen(cmd))
         if len(procs) == 4:
@@ -53,7 +53,28 @@ def run():
     def two():
         ops.gemm_x3(m1, p1, ops.EPI_RELU, out=hid)
         ops.gemm_x3(hid, p2, ops.EPI_RES_LN, residual=x, gamma=gam, beta=bet, out=y)
-    calls = [("two launches (gemm_x3 up + down)", two)]
+    # the whole layer tail: synthetic but well-formed operands (one cloud per 40 row tiles)
+    n_tiles = M // 128
+    tiles_per_cloud = 40
+    n_clouds = (n_tiles + tiles_per_cloud - 1) // tiles_per_cloud
+    tile_cloud = (torch.arange(n_tiles, device=dev) // tiles_per_cloud).int()
+    crow0 = (torch.arange(n_clouds, device=dev) * tiles_per_cloud * 128).int()
+    clen = torch.full((n_clouds,), tiles_per_cloud * 128 - 17, device=dev, dtype=torch.int32)
+    clen[-1] = M - int(crow0[-1]) - 5
+    Wqkv = torch.randn(768, 256, device=dev, generator=g) / 16
+    Wm = torch.randn(256, 256, device=dev, generator=g) / 16
+    Qp, part = ops.gemm_qkv(x, ops.split_planes(Wqkv), 256, tile_cloud, crow0, clen, 0)
+    Qf, xf = ops.act_layout(Qp, True), ops.act_layout(x, True)  # the fused tail takes fragment-major operands
+    kv = ops.kv_finalize(part, crow0, clen, 0, 0, n_clouds, n_clouds)
+    att = torch.empty(M, 256, device=dev)
+    pm = ops.split_planes(Wm)
+    ffn_img = ops.pack_ffn(W1, W2)
+
+    def unfused_tail():
+        a = ops.attn_apply(Qp, 256, kv, tile_cloud, 0, clen, M)
+        ops.gemm_x3(a, pm, ops.EPI_RES_LN, residual=x, gamma=gam, beta=bet, out=hid[:, :256].contiguous() if False else att)
+        ops.ffn_x3(att, ffn_img, x, gam, bet, out=y)
+    calls = [("two launches (gemm_x3 up + down)", two), ("apply + merge GEMM + fused FFN (3 launches)", unfused_tail)]
     for tag in os.environ.get("T_TAGS", "").split(","):
         for bits, label in VARIANTS:
             f = os.path.join(ROOT, "tools", "_tabl" + tag, "t_%d.so" % bits)
@@ -63,9 +84,22 @@ def run():
             pk = lib.scream_pack_ffn_x3; pk.restype = ctypes.c_int; pk.argtypes = [V, V, V, V]
             img = torch.empty(lib.scream_ffn_image_bytes(), device=dev, dtype=torch.uint8)
             assert pk(W1.data_ptr(), W2.data_ptr(), img.data_ptr(), st) == 0
-            calls.append(((tag + " " if tag else "") + "fused: " + label,
-                          (lambda fn=fn, img=img: fn(m1.data_ptr(), 256, img.data_ptr(), x.data_ptr(), 256, gam.data_ptr(), bet.data_ptr(), y.data_ptr(), 256, M, st))))
-    print("%-38s %9s %9s %9s %10s %9s  (M=%d; FFN up+down = %.1f GFLOP)" % ("variant", "ms", "sclk MHz", "power W", "J/launch", "TFLOP/s", M, 4.0 * M * 256 * 1024 / 1e9))
+            if not os.environ.get("T_NO_FFN"):
+                calls.append(((tag + " " if tag else "") + "fused FFN: " + label,
+                              (lambda fn=fn, img=img: fn(m1.data_ptr(), 256, img.data_ptr(), x.data_ptr(), 256, gam.data_ptr(), bet.data_ptr(), y.data_ptr(), 256, M, st))))
+            I32 = ctypes.c_int32
+            ft = lib.scream_layer_tail_x3_f32; ft.restype = ctypes.c_int
+            ft.argtypes = [V, V, V, I32, V, V, V, V, V, V, V, V, I64, V]
+            pt = lib.scream_pack_tail_x3; pt.restype = ctypes.c_int; pt.argtypes = [V, V, V, V, V]
+            kf = lib.scream_kv_finalize_x3; kf.restype = ctypes.c_int; kf.argtypes = [V, V, V, I64, I32, I32, V, V]
+            timg = torch.empty(lib.scream_tail_image_bytes(), device=dev, dtype=torch.uint8)
+            assert pt(Wm.data_ptr(), W1.data_ptr(), W2.data_ptr(), timg.data_ptr(), st) == 0
+            kvi = torch.zeros(n_clouds, lib.scream_kv_image_bytes(), device=dev, dtype=torch.uint8)
+            assert kf(part.data_ptr(), crow0.data_ptr(), clen.data_ptr(), 0, 0, n_clouds, kvi.data_ptr(), st) == 0
+            calls.append(((tag + " " if tag else "") + "fused tail: " + label,
+                          (lambda ft=ft, timg=timg, kvi=kvi: ft(Qf.data_ptr(), kvi.data_ptr(), tile_cloud.data_ptr(), 0, clen.data_ptr(), xf.data_ptr(),
+                                                                timg.data_ptr(), gam.data_ptr(), bet.data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(), M, st))))
+    print("%-46s %9s %9s %9s %10s %9s  (M=%d; FFN up+down = %.1f GFLOP)" % ("variant", "ms", "sclk MHz", "power W", "J/launch", "TFLOP/s", M, 4.0 * M * 256 * 1024 / 1e9))
     for label, call in calls:
         call(); torch.cuda.synchronize(); time.sleep(0.4)
         t0 = time.time(); n = 0
@@ -76,7 +110,8 @@ def run():
         win = [s for s in samples if t0 + 0.5 < s[0] < t1 - 0.1]
         sclk = sum(s[1] for s in win) / max(len(win), 1); pw = sum(s[2] for s in win) / max(len(win), 1)
         ms = (t1 - t0) / n * 1e3
-        print("%-38s %9.3f %9.0f %9.0f %10.3f %9.1f" % (label, ms, sclk, pw, pw * ms * 1e-3, 4.0 * M * 256 * 1024 / ms / 1e9), flush=True)
+        fl = (2.0 * M * 256 * 2304 if ("tail" in label or "3 launches" in label) else 4.0 * M * 256 * 1024)
+        print("%-46s %9.3f %9.0f %9.0f %10.3f %9.1f" % (label, ms, sclk, pw, pw * ms * 1e-3, fl / ms / 1e9), flush=True)
         time.sleep(0.5)
     stop[0] = True; th.join()
 
