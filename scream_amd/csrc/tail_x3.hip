@@ -36,6 +36,9 @@
 #ifndef T_ABLATE
 #define T_ABLATE 0
 #endif
+#ifndef T_PF
+#define T_PF 3  // register sets of weight fragments in tail_x3_kernel: fragments are read T_PF - 1 MFMA groups ahead
+#endif
 #include <type_traits>
 
 #include "common.h"
@@ -86,6 +89,18 @@ __device__ __forceinline__ void lds_only_barrier() {  // lgkmcnt(0) + workgroup 
 __host__ __device__ __forceinline__ int chunk_k(int s2, int half, int j) { return 8 * (2 * s2 + (j >> 2)) + 4 * half + (j & 3); }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// One 1 KiB LDS-DMA piece, number k (0 .. 3) of a group of four that share their address registers: the instruction's
+// immediate offset moves the global source AND the LDS destination, so four pieces cost one address computation and
+// one M0 write (k folds to a constant after unrolling; the builtin wants a literal).
+__device__ __forceinline__ void dma_1k(const char* src_lane, char* dst, int k) {
+    switch (k) {
+        case 0: __builtin_amdgcn_global_load_lds((gptr_t)src_lane, (lptr_t)dst, 16, 0, 0); break;
+        case 1: __builtin_amdgcn_global_load_lds((gptr_t)src_lane, (lptr_t)dst, 16, 1024, 0); break;
+        case 2: __builtin_amdgcn_global_load_lds((gptr_t)src_lane, (lptr_t)dst, 16, 2048, 0); break;
+        default: __builtin_amdgcn_global_load_lds((gptr_t)src_lane, (lptr_t)dst, 16, 3072, 0); break;
+    }
+}
 
 // one 1 KiB weight fragment (16 bytes per lane) from the current stage
 __device__ __forceinline__ bf16x8 ld_frag(const char* p) {
@@ -148,9 +163,7 @@ __global__ __launch_bounds__(TT, 1) void ffn_x3_kernel(const float* __restrict__
     auto dma_piece = [&](unsigned q, int u) {
         if ((T_ABLATE & 1) && q >= 2) return;
         const unsigned src = q % (unsigned)FFN_STAGES, slot = q % (unsigned)T_SLOTS;
-        const int piece = wave * 12 + u;
-        __builtin_amdgcn_global_load_lds((gptr_t)(w_lane + (size_t)src * T_STAGE + piece * 1024),
-                                         (lptr_t)(smem + slot * T_STAGE + piece * 1024), 16, 0, 0);
+        dma_1k(w_lane + (size_t)src * T_STAGE + (wave * 12 + (u & ~3)) * 1024, smem + slot * T_STAGE + (wave * 12 + (u & ~3)) * 1024, u & 3);
     };
 
     unsigned q = 0;  // next stage to be consumed
@@ -361,6 +374,13 @@ constexpr int KV_PLANES_BYTES = 8 * 3 * 2 * 1024;            // per cloud: [head
 constexpr int KV_IMAGE_BYTES = KV_PLANES_BYTES + 8 * 32 * 4;  // + Ksum [head][32] fp32
 
 __device__ __forceinline__ void ld_asm(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p)); }
+// four loads 1 KiB apart from ONE address register (immediate offsets): the pieces a = 0 .. 3 of a fragment-major segment
+__device__ __forceinline__ void ld_asm4(f32x4 (&d)[4], const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d[0]) : "v"(p));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(d[1]) : "v"(p));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(d[2]) : "v"(p));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(d[3]) : "v"(p));
+}
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 
 struct HeadOps {   // what the apply of one head needs, as loaded
@@ -405,9 +425,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
     auto dma_piece = [&](unsigned q, int u) {
         if ((T_ABLATE & 1) && q >= 2) return;
         const unsigned src = q % (unsigned)TAIL_STAGES, slot = q % (unsigned)T_SLOTS;
-        const int piece = wave * 12 + u;
-        __builtin_amdgcn_global_load_lds((gptr_t)(w_lane + (size_t)src * T_STAGE + piece * 1024),
-                                         (lptr_t)(smem + slot * T_STAGE + piece * 1024), 16, 0, 0);
+        dma_1k(w_lane + (size_t)src * T_STAGE + (wave * 12 + (u & ~3)) * 1024, smem + slot * T_STAGE + (wave * 12 + (u & ~3)) * 1024, u & 3);
     };
     unsigned q = 0;  // next stage to be consumed
 #pragma unroll
@@ -425,17 +443,21 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         if (T_ABLATE & 16) return;
         const char* kp = kvc + h * (3 * 2 * 1024) + lane * 16;
         const float* sp = reinterpret_cast<const float*>(kvc + KV_PLANES_BYTES) + 32 * h + 4 * half;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) ld_asm(o.q[a], frag_ptr(Q, grp, h, a));
-#pragma unroll
-        for (int f = 0; f < 6; ++f) ld_asm(o.kv[f], kp + f * 1024);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) ld_asm(o.ks[a], sp + 8 * a);
+        ld_asm4(o.q, frag_ptr(Q, grp, h, 0));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(o.kv[0]) : "v"(kp));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(o.kv[1]) : "v"(kp));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(o.kv[2]) : "v"(kp));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(o.kv[3]) : "v"(kp));
+        ld_asm(o.kv[4], kp + 4 * 1024);
+        ld_asm(o.kv[5], kp + 5 * 1024);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(o.ks[0]) : "v"(sp));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(o.ks[1]) : "v"(sp));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(o.ks[2]) : "v"(sp));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:96" : "=v"(o.ks[3]) : "v"(sp));
     };
     auto req_x = [&](f32x4 (&xs)[4], int64_t grp, int blk) {
         if (T_ABLATE & 16) return;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) ld_asm(xs[a], frag_ptr(xres, grp, blk, a));
+        ld_asm4(xs, frag_ptr(xres, grp, blk, 0));
     };
     auto pin_head = [&](HeadOps& o) {
 #pragma unroll
@@ -578,16 +600,16 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             if (h == 0) req_head(op, grp, kvc, 2);
             __builtin_amdgcn_sched_barrier(0);
             const char* wb = smem + (q % T_SLOTS) * T_STAGE + lane * 16;
-            bf16x8 wf[3][3];
+            bf16x8 wf[T_PF][3];
 #pragma unroll
-            for (int g0 = 0; g0 < 2; ++g0)
+            for (int g0 = 0; g0 < T_PF - 1; ++g0)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) wf[g0][p] = ld_frag(wb + (p * 16 + g0) * 1024);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {  // g = blk * 2 + s2
-                if (g + 2 < 16) {
+                if (g + T_PF - 1 < 16) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) wf[(g + 2) % 3][p] = ld_frag(wb + (p * 16 + g + 2) * 1024);
+                    for (int p = 0; p < 3; ++p) wf[(g + T_PF - 1) % T_PF][p] = ld_frag(wb + (p * 16 + g + T_PF - 1) * 1024);
                 }
                 if (g == 4 && RIDE && h + 2 < 8) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -596,7 +618,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 }
                 if (g >= 4) dma_piece(q + 2, g - 4);
                 if (RIDE) apply_ride(g, ap_next, S, tile);
-                mfma6(acc[g >> 1], wf[g % 3], ap[g & 1]);
+                mfma6(acc[g >> 1], wf[g % T_PF], ap[g & 1]);
             }
             ++q;
         };
@@ -681,21 +703,21 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             if (XLOAD >= 0) req_x(xs, grp, XLOAD);
             __builtin_amdgcn_sched_barrier(0);
             const char* wb = smem + (q % T_SLOTS) * T_STAGE + lane * 16;
-            bf16x8 wf[3][3];
+            bf16x8 wf[T_PF][3];
 #pragma unroll
-            for (int g0 = 0; g0 < 2; ++g0)
+            for (int g0 = 0; g0 < T_PF - 1; ++g0)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) wf[g0][p] = ld_frag(wb + (p * 16 + g0) * 1024);
 #pragma unroll
             for (int e = 0; e < 16; ++e) hT[e] = 0.f;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                if (g + 2 < 16) {
+                if (g + T_PF - 1 < 16) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) wf[(g + 2) % 3][p] = ld_frag(wb + (p * 16 + g + 2) * 1024);
+                    for (int p = 0; p < 3; ++p) wf[(g + T_PF - 1) % T_PF][p] = ld_frag(wb + (p * 16 + g + T_PF - 1) * 1024);
                 }
                 if (g < 12) dma_piece(q + 2, g);
-                mfma6(hT, wf[g % 3], mp[g]);
+                mfma6(hT, wf[g % T_PF], mp[g]);
             }
             ++q;
         };
@@ -717,16 +739,16 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             if (RIDE == 1 && has_next) req_head(op, grp_next, kvc_next, 0);
             __builtin_amdgcn_sched_barrier(0);
             const char* wb = smem + (q % T_SLOTS) * T_STAGE + lane * 16;
-            bf16x8 wf[3][3];
+            bf16x8 wf[T_PF][3];
 #pragma unroll
-            for (int g0 = 0; g0 < 2; ++g0)
+            for (int g0 = 0; g0 < T_PF - 1; ++g0)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) wf[g0][p] = ld_frag(wb + (p * 16 + g0) * 1024);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {  // g = blk * 2 + s2
-                if (g + 2 < 16) {
+                if (g + T_PF - 1 < 16) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) wf[(g + 2) % 3][p] = ld_frag(wb + (p * 16 + g + 2) * 1024);
+                    for (int p = 0; p < 3; ++p) wf[(g + T_PF - 1) % T_PF][p] = ld_frag(wb + (p * 16 + g + T_PF - 1) * 1024);
                 }
                 if (RIDE == 2 && g == 4) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -740,7 +762,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 }
                 if (RIDE == 2) apply_ride(g, apA, S_next, tile_next);
                 if (decltype(with_split)::value && (g & 1) == 0) split_pair(g >> 1, hout);
-                mfma6(acc[g >> 1], wf[g % 3], hin[g & 1]);
+                mfma6(acc[g >> 1], wf[g % T_PF], hin[g & 1]);
             }
             ++q;
         };
