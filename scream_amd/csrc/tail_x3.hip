@@ -43,6 +43,22 @@
 
 #include "common.h"
 
+// -DT_STAMPS (tools/tail_stamps.py): s_memtime stamps of the phases of the SECOND tile of every block, lane 0 of each wave.
+// Diagnostic build only -- run tools/asm_inflight_check.py on it first: the extra registers can push hipcc into spilling
+// a pending load destination (it did, with one stamp per stage).
+#ifdef T_STAMPS
+__device__ long long t_stamps[256 * 4 * 8];
+extern "C" int scream_tail_stamps_read(long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(t_stamps), sizeof(long long) * 256 * 4 * 8);
+}
+#define TSTAMP(slot)                                                                                 \
+    do {                                                                                             \
+        if (stamp_on && lane == 0) t_stamps[((int)blockIdx.x * 4 + wave) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define TSTAMP(slot) do {} while (0)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -383,8 +399,7 @@ __device__ __forceinline__ void ld_asm4(f32x4 (&d)[4], const void* p) {
 }
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 
-struct HeadOps {   // what the apply of one head needs, as loaded
-    f32x4 q[4];    // Q'[row, 32 h + 8 a + 4 half .. + 4], a = 0 .. 3
+struct HeadOps {   // the per-cloud operands of one head's apply, as loaded (Q' travels separately: f32x4 q[4], pieces a = 0 .. 3)
     f32x4 kv[6];   // KV_h^T fragments [plane][step], 16 bytes per lane
     f32x4 ks[4];   // Ksum[h][8 a + 4 half .. + 4]
 };
@@ -439,11 +454,14 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
     // spills it to scratch right behind the asm statement when registers are short there.
     // grp: first float of the wave's 32-row group (8192 floats in either layout); segment seg, piece a, this lane:
     auto frag_ptr = [&](const float* base, int64_t grp, int seg, int a) { return base + grp + ((seg * 4 + a) * 64 + lane) * 4; };
-    auto req_head = [&](HeadOps& o, int64_t grp, const char* kvc, int h) {
+    auto req_q = [&](f32x4 (&qb)[4], int64_t grp, int h) {  // Q' of head h: the one operand that comes from HBM
+        if (T_ABLATE & 16) return;
+        ld_asm4(qb, frag_ptr(Q, grp, h, 0));
+    };
+    auto req_head = [&](HeadOps& o, const char* kvc, int h) {  // KV^T fragments and Ksum of head h: L2-hot per-cloud data
         if (T_ABLATE & 16) return;
         const char* kp = kvc + h * (3 * 2 * 1024) + lane * 16;
         const float* sp = reinterpret_cast<const float*>(kvc + KV_PLANES_BYTES) + 32 * h + 4 * half;
-        ld_asm4(o.q, frag_ptr(Q, grp, h, 0));
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(o.kv[0]) : "v"(kp));
         asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(o.kv[1]) : "v"(kp));
         asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(o.kv[2]) : "v"(kp));
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
     };
     auto pin_head = [&](HeadOps& o) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) { pin(o.q[a]); pin(o.ks[a]); }
+        for (int a = 0; a < 4; ++a) pin(o.ks[a]);
 #pragma unroll
         for (int f = 0; f < 6; ++f) pin(o.kv[f]);
     };
@@ -476,7 +494,12 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             for (int k = 0; k < 4; ++k) t[4 * a + k] += (T_ABLATE & 16) ? 1.0f : xs[a][k];
     };
 
-    HeadOps op;             // ONE operand buffer: a stage consumes it in its first groups and re-requests into it right after
+    // KV^T / Ksum: ONE buffer, consumed in a stage's first groups and re-requested right after (a third of a stage of
+    // lead is plenty for L2-hot data).  Q' comes from HBM and gets TWO buffers, alternating by head, requested at the
+    // top of the stage BEFORE the one that consumes it -- with a single buffer the merge stages took 6.6 k cycles against
+    // 3.8 k for an FFN stage (tools/tail_stamps.py).
+    HeadOps op;
+    f32x4 qA[4], qB[4];     // Q' of even / odd heads
     f32x4 xs[4], xs2[4];    // x segments (xs2: only segment 7 of the norm1 residual)
     bf16x8 apA[2][3], apB[2][3];  // planes of att_h^T, the B operand of the merge GEMM: heads of even / odd index
     f32x16 aT;              // att_h^T tile of the head being applied
@@ -484,15 +507,15 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
     float Zs = 0.f;
 
     // ---- apply of one head (models/transformer.py:41-42), in pieces that ride inside the groups of another stage ----
-    auto apply_qsplit = [&](int tile_tag) {
+    auto apply_qsplit = [&](f32x4 (&qb)[4], int tile_tag) {
         if (T_ABLATE & 16) {
             const f32x4 f = {(float)lane, 1.0f, 0.5f, (float)tile_tag};
             split3(f, f, qp[0][0], qp[0][1], qp[0][2]);
             split3(f, f, qp[1][0], qp[1][1], qp[1][2]);
             return;
         }
-        split3(op.q[0], op.q[1], qp[0][0], qp[0][1], qp[0][2]);
-        split3(op.q[2], op.q[3], qp[1][0], qp[1][1], qp[1][2]);
+        split3(qb[0], qb[1], qp[0][0], qp[0][1], qp[0][2]);
+        split3(qb[2], qb[3], qp[1][0], qp[1][1], qp[1][2]);
     };
     auto apply_mfma = [&](int s2) {
         bf16x8 w[3];
@@ -504,12 +527,12 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         }
         mfma6_free(aT, w, qp[s2]);
     };
-    auto apply_z = [&]() {  // Z = 1 / (Q'.Ksum + 1e-6); lanes r and r + 32 share row r
+    auto apply_z = [&](f32x4 (&qb)[4]) {  // Z = 1 / (Q'.Ksum + 1e-6); lanes r and r + 32 share row r
         float zp = 0.f;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) zp += op.q[a][k] * op.ks[a][k];
+            for (int k = 0; k < 4; ++k) zp += qb[a][k] * op.ks[a][k];
         zp += __shfl_xor(zp, 32);
         Zs = 1.0f / (zp + 1e-6f);
     };
@@ -527,11 +550,11 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         }
     };
     // the pieces of one apply as they ride in group g of a 16-group stage: operands consumed in groups 0-3
-    auto apply_ride = [&](int g, bf16x8 (&ap)[2][3], float S, int tile_tag) {
-        if (g == 0) apply_qsplit(tile_tag);
+    auto apply_ride = [&](f32x4 (&qb)[4], int g, bf16x8 (&ap)[2][3], float S, int tile_tag) {
+        if (g == 0) apply_qsplit(qb, tile_tag);
         if (g == 1) apply_mfma(0);
         if (g == 2) apply_mfma(1);
-        if (g == 3) apply_z();
+        if (g == 3) apply_z(qb);
         if (g >= 4 && g < 12) apply_split_pair(g - 4, ap, S);
     };
 
@@ -545,15 +568,25 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         S = (float)cloud_len[cl];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            req_head(op, grp, kvc, h);
+            req_q(qA, grp, h);
+            req_head(op, kvc, h);
             VM_WAIT(0);
+            pin_x(qA);
             pin_head(op);
 #pragma unroll
-            for (int g = 0; g < 12; ++g) apply_ride(g, h == 0 ? apA : apB, S, tile);
+            for (int g = 0; g < 12; ++g) apply_ride(qA, g, h == 0 ? apA : apB, S, tile);
         }
     }
 
+#ifdef T_STAMPS
+    int tile_no = 0;
+#endif
     while (tile < n_tiles) {
+#ifdef T_STAMPS
+        const bool stamp_on = tile_no == 1;
+        ++tile_no;
+#endif
+        TSTAMP(0);  // tile start
         f32x16 acc[8];
 #pragma unroll
         for (int b = 0; b < 8; ++b)
@@ -578,7 +611,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         //   groups 0-3:  stages 1 .. 6 consume the operands of head h + 1 (requested by stage h - 1) -- its apply rides here;
         //   group 4:     the operand buffer is re-requested for head h + 2 (stage 0: requested at the top);
         //   groups 4-15: the stage's weight pieces, AFTER every row request, so that the next barrier's vmcnt(12) covers them.
-        auto stage_merge = [&](auto hh, bf16x8 (&ap)[2][3], bf16x8 (&ap_next)[2][3]) {
+        auto stage_merge = [&](auto hh, bf16x8 (&ap)[2][3], bf16x8 (&ap_next)[2][3], f32x4 (&q_cons)[4], f32x4 (&q_req)[4]) {
             constexpr int h = decltype(hh)::value;
             constexpr bool RIDE = h >= 1 && h <= 6;
             // stage 0 of a tile: everything older was drained at the end of the previous tile (only its y stores may
@@ -588,7 +621,10 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             if (h > 0) {
                 pin_x(xs);
                 add_x(acc[h > 0 ? h - 1 : 0], xs);
-                if (RIDE) pin_head(op);
+                if (RIDE) {
+                    pin_head(op);
+                    pin_x(q_cons);
+                }
             }
             if (h == 7) {
                 pin_x(xs2);
@@ -597,7 +633,8 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             __builtin_amdgcn_sched_barrier(0);
             if (h < 7) req_x(xs, grp, h);
             if (h == 6) req_x(xs2, grp, 7);
-            if (h == 0) req_head(op, grp, kvc, 2);
+            if (h + 2 < 8) req_q(q_req, grp, h + 2);  // consumed by stage h + 1
+            if (h == 0) req_head(op, kvc, 2);
             __builtin_amdgcn_sched_barrier(0);
             const char* wb = smem + (q % T_SLOTS) * T_STAGE + lane * 16;
             bf16x8 wf[T_PF][3];
@@ -613,11 +650,11 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 }
                 if (g == 4 && RIDE && h + 2 < 8) {
                     __builtin_amdgcn_sched_barrier(0);
-                    req_head(op, grp, kvc, h + 2);
+                    req_head(op, kvc, h + 2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (g >= 4) dma_piece(q + 2, g - 4);
-                if (RIDE) apply_ride(g, ap_next, S, tile);
+                if (RIDE) apply_ride(q_cons, g, ap_next, S, tile);
                 mfma6(acc[g >> 1], wf[g % T_PF], ap[g & 1]);
             }
             ++q;
@@ -625,16 +662,17 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         constexpr std::integral_constant<bool, true> yes{};
         constexpr std::integral_constant<bool, false> no{};
 #define HEAD(n) std::integral_constant<int, n>{}
-        //            head   planes  planes of head + 1
-        stage_merge(HEAD(0), apA, apB);
-        stage_merge(HEAD(1), apB, apA);
-        stage_merge(HEAD(2), apA, apB);
-        stage_merge(HEAD(3), apB, apA);
-        stage_merge(HEAD(4), apA, apB);
-        stage_merge(HEAD(5), apB, apA);
-        stage_merge(HEAD(6), apA, apB);
-        stage_merge(HEAD(7), apB, apA);
+        //            head   planes  planes of head + 1   Q' consumed (head + 1)   Q' requested (head + 2)
+        stage_merge(HEAD(0), apA, apB, qB, qA);
+        stage_merge(HEAD(1), apB, apA, qA, qB);
+        stage_merge(HEAD(2), apA, apB, qB, qA);
+        stage_merge(HEAD(3), apB, apA, qA, qB);
+        stage_merge(HEAD(4), apA, apB, qB, qA);
+        stage_merge(HEAD(5), apB, apA, qA, qB);
+        stage_merge(HEAD(6), apA, apB, qB, qA);
+        stage_merge(HEAD(7), apB, apA, qA, qB);
 
+        TSTAMP(1);  // end of the merge phase
         // ---- m1 = LayerNorm1(merge + x) (models/transformer.py:84), straight into the B-operand planes of FFN-up ---
         bf16x8 mp[16][3];
         {
@@ -678,6 +716,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
         }
 
+        TSTAMP(2);  // end of norm1
         // ---- FFN (as ffn_x3_kernel); x segments 0 .. 7 (the norm2 residual) are added under the first eight down stages
         f32x16 hT;
         bf16x8 hpA[2][3], hpB[2][3];
@@ -734,9 +773,15 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 pin_x(xs);
                 add_x(acc[XADD >= 0 ? XADD : 0], xs);
             }
-            if (RIDE == 2) pin_head(op);  // (untouched registers when the block has no next tile: the results are never used)
+            if (RIDE == 2) {  // (untouched registers when the block has no next tile: the results are never used)
+                pin_head(op);
+                pin_x(qA);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if (RIDE == 1 && has_next) req_head(op, grp_next, kvc_next, 0);
+            if (RIDE == 1 && has_next) {
+                req_q(qA, grp_next, 0);
+                req_head(op, kvc_next, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             const char* wb = smem + (q % T_SLOTS) * T_STAGE + lane * 16;
             bf16x8 wf[T_PF][3];
@@ -752,7 +797,10 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 }
                 if (RIDE == 2 && g == 4) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (has_next) req_head(op, grp_next, kvc_next, 1);
+                    if (has_next) {  // head 1 into the buffers head 0 has just left (a second Q' buffer here, at the top of
+                        req_q(qA, grp_next, 1);  // the stage, was spilled by hipcc right behind its loads)
+                        req_head(op, kvc_next, 1);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (RIDE == 2) {
@@ -760,7 +808,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 } else {
                     if (g < 12) dma_piece(q + 2, g);
                 }
-                if (RIDE == 2) apply_ride(g, apA, S_next, tile_next);
+                if (RIDE == 2) apply_ride(qA, g, apA, S_next, tile_next);
                 if (decltype(with_split)::value && (g & 1) == 0) split_pair(g >> 1, hout);
                 mfma6(acc[g >> 1], wf[g % T_PF], hin[g & 1]);
             }
@@ -795,13 +843,16 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         // head is applied here in the open (12 MFMAs), so that nothing pending lives across the norm2 block, and the y
         // stores below are YOUNGER than every load a later counted wait is meant to cover (stores retire out of order with
         // respect to loads, gemm_x3.hip; stage 0 of the next tile starts without a vector-memory wait).
+        TSTAMP(3);  // end of the last stage
         VM_WAIT(0);
         if (has_next) {
             pin_head(op);
+            pin_x(qA);
 #pragma unroll
-            for (int g = 0; g < 12; ++g) apply_ride(g, apB, S_next, tile_next);
+            for (int g = 0; g < 12; ++g) apply_ride(qA, g, apB, S_next, tile_next);
         }
 
+        TSTAMP(4);  // after the open apply of the next tile's head 1
         // ---- y = LayerNorm2(x + ffn) (the residual is already in the accumulators), stored fragment-major ------------
         {
             float sum = 0.f;
@@ -837,6 +888,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                     if (!(T_ABLATE & 16) || o[0] + o[1] + o[2] + o[3] == 123.456f) *reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256) = o;
                 }
         }
+        TSTAMP(5);  // tile end
         tile = tile_next;
         grp = grp_next;
         kvc = kvc_next;
