@@ -587,6 +587,11 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         ++tile_no;
 #endif
         TSTAMP(0);  // tile start
+        // The last MFMA group of every stage is DEFERRED across the barrier: its weight fragments are read into wfd, and
+        // the next stage issues it right after the first fragment reads of its own -- 6 MFMAs (192 cycles) of work with
+        // register operands exactly where a lone in-order wave otherwise waits for the LDS (tools/tail_stamps.py: 3.8 k
+        // cycles per 3.07 k-cycle stage).  `flush` arguments below name the deferred group of the preceding stage.
+        bf16x8 wfd[3];
         f32x16 acc[8];
 #pragma unroll
         for (int b = 0; b < 8; ++b)
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         //   groups 0-3:  stages 1 .. 6 consume the operands of head h + 1 (requested by stage h - 1) -- its apply rides here;
         //   group 4:     the operand buffer is re-requested for head h + 2 (stage 0: requested at the top);
         //   groups 4-15: the stage's weight pieces, AFTER every row request, so that the next barrier's vmcnt(12) covers them.
-        auto stage_merge = [&](auto hh, bf16x8 (&ap)[2][3], bf16x8 (&ap_next)[2][3], f32x4 (&q_cons)[4], f32x4 (&q_req)[4]) {
+        auto stage_merge = [&](auto hh, bf16x8 (&ap)[2][3], bf16x8 (&ap_next)[2][3], f32x4 (&q_cons)[4], f32x4 (&q_req)[4], auto flush) {
             constexpr int h = decltype(hh)::value;
             constexpr bool RIDE = h >= 1 && h <= 6;
             // stage 0 of a tile: everything older was drained at the end of the previous tile (only its y stores may
@@ -642,11 +647,13 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             for (int g0 = 0; g0 < T_PF - 1; ++g0)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) wf[g0][p] = ld_frag(wb + (p * 16 + g0) * 1024);
+            flush();
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {  // g = blk * 2 + s2
+            for (int g = 0; g < 15; ++g) {  // g = blk * 2 + s2; group 15 is deferred to the next stage
                 if (g + T_PF - 1 < 16) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) wf[(g + T_PF - 1) % T_PF][p] = ld_frag(wb + (p * 16 + g + T_PF - 1) * 1024);
+                    for (int p = 0; p < 3; ++p)
+                        (g + T_PF - 1 == 15 ? wfd[p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag(wb + (p * 16 + g + T_PF - 1) * 1024);
                 }
                 if (g == 4 && RIDE && h + 2 < 8) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -654,6 +661,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (g >= 4) dma_piece(q + 2, g - 4);
+                if (g == 14) dma_piece(q + 2, 11);  // (group 15 is deferred: the twelfth piece goes out with the eleventh)
                 if (RIDE) apply_ride(q_cons, g, ap_next, S, tile);
                 mfma6(acc[g >> 1], wf[g % T_PF], ap[g & 1]);
             }
@@ -662,15 +670,19 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         constexpr std::integral_constant<bool, true> yes{};
         constexpr std::integral_constant<bool, false> no{};
 #define HEAD(n) std::integral_constant<int, n>{}
-        //            head   planes  planes of head + 1   Q' consumed (head + 1)   Q' requested (head + 2)
-        stage_merge(HEAD(0), apA, apB, qB, qA);
-        stage_merge(HEAD(1), apB, apA, qA, qB);
-        stage_merge(HEAD(2), apA, apB, qB, qA);
-        stage_merge(HEAD(3), apB, apA, qA, qB);
-        stage_merge(HEAD(4), apA, apB, qB, qA);
-        stage_merge(HEAD(5), apB, apA, qA, qB);
-        stage_merge(HEAD(6), apA, apB, qB, qA);
-        stage_merge(HEAD(7), apB, apA, qA, qB);
+        auto flush_none = [&]() {};
+        auto flush_mergeA = [&]() { mfma6_free(acc[7], wfd, apA[1]); };  // deferred group of a merge stage of an even head
+        auto flush_mergeB = [&]() { mfma6_free(acc[7], wfd, apB[1]); };
+        //            head   planes  planes of head + 1   Q' consumed (head + 1)   Q' requested (head + 2)   deferred group of
+        stage_merge(HEAD(0), apA, apB, qB, qA, flush_none);   // (the previous tile ended flushed)
+        stage_merge(HEAD(1), apB, apA, qA, qB, flush_mergeA);
+        stage_merge(HEAD(2), apA, apB, qB, qA, flush_mergeB);
+        stage_merge(HEAD(3), apB, apA, qA, qB, flush_mergeA);
+        stage_merge(HEAD(4), apA, apB, qB, qA, flush_mergeB);
+        stage_merge(HEAD(5), apB, apA, qA, qB, flush_mergeA);
+        stage_merge(HEAD(6), apA, apB, qB, qA, flush_mergeB);
+        stage_merge(HEAD(7), apB, apA, qA, qB, flush_mergeA);
+        flush_mergeB();  // norm1 needs the finished accumulators
 
         TSTAMP(1);  // end of the merge phase
         // ---- m1 = LayerNorm1(merge + x) (models/transformer.py:84), straight into the B-operand planes of FFN-up ---
@@ -734,7 +746,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             }
         };
         // XLOAD: x segment to request in this stage (-1: none)
-        auto stage_up = [&](auto first, auto xload) {
+        auto stage_up = [&](auto first, auto xload, auto flush) {
             constexpr int XLOAD = decltype(xload)::value;
             // FIRST: the norm1 block above used ordinary loads (gamma, beta), which hipcc waits for with vmcnt(0)
             if (decltype(first)::value) ring_barrier<0>(); else ring_barrier<12>();
@@ -747,13 +759,15 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             for (int g0 = 0; g0 < T_PF - 1; ++g0)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) wf[g0][p] = ld_frag(wb + (p * 16 + g0) * 1024);
+            flush();
 #pragma unroll
             for (int e = 0; e < 16; ++e) hT[e] = 0.f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
+            for (int g = 0; g < 15; ++g) {  // group 15 (hT += wfd . mp[15]) is deferred to the next stage
                 if (g + T_PF - 1 < 16) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) wf[(g + T_PF - 1) % T_PF][p] = ld_frag(wb + (p * 16 + g + T_PF - 1) * 1024);
+                    for (int p = 0; p < 3; ++p)
+                        (g + T_PF - 1 == 15 ? wfd[p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag(wb + (p * 16 + g + T_PF - 1) * 1024);
                 }
                 if (g < 12) dma_piece(q + 2, g);
                 mfma6(hT, wf[g % T_PF], mp[g]);
@@ -764,7 +778,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         // RIDE (the tile's last two stages, when the FFN's operand planes are dead and registers are available again):
         // 1 = requests the operands of the next tile's head 0; 2 = the apply of that head rides here, and head 1 is
         // requested behind it (applied in the open right after the stage).
-        auto stage_down = [&](bf16x8 (&hin)[2][3], bf16x8 (&hout)[2][3], auto with_split, auto xadd, auto ride) {
+        auto stage_down = [&](bf16x8 (&hin)[2][3], bf16x8 (&hout)[2][3], auto with_split, auto xadd, auto ride, auto flush) {
             constexpr int XADD = decltype(xadd)::value;
             constexpr int RIDE = decltype(ride)::value;
             ring_barrier<12>();
@@ -789,11 +803,13 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             for (int g0 = 0; g0 < T_PF - 1; ++g0)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) wf[g0][p] = ld_frag(wb + (p * 16 + g0) * 1024);
+            flush();
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {  // g = blk * 2 + s2
+            for (int g = 0; g < 15; ++g) {  // g = blk * 2 + s2; group 15 (acc[7] += wfd . hin[1]) is deferred to the next stage
                 if (g + T_PF - 1 < 16) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) wf[(g + T_PF - 1) % T_PF][p] = ld_frag(wb + (p * 16 + g + T_PF - 1) * 1024);
+                    for (int p = 0; p < 3; ++p)
+                        (g + T_PF - 1 == 15 ? wfd[p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag(wb + (p * 16 + g + T_PF - 1) * 1024);
                 }
                 if (RIDE == 2 && g == 4) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -805,6 +821,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 }
                 if (RIDE == 2) {
                     if (g >= 4) dma_piece(q + 2, g - 4);
+                    if (g == 14) dma_piece(q + 2, 11);  // (group 15 is deferred: the twelfth piece goes out with the eleventh)
                 } else {
                     if (g < 12) dma_piece(q + 2, g);
                 }
@@ -819,25 +836,30 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         // stage order (= image order): W1_0 | W1_c, W2_{c-1} for c = 1 .. 31 | W2_31.  The norm2 residual: the up stage of
         // chunk c requests x segment c - 1, the down stage of chunk c - 1 that follows adds it (c - 1 < 8) -- the first
         // four pair iterations are peeled so that every accumulator index is a compile-time constant.
-        stage_up(yes, none);
+        auto flush_up = [&]() { mfma6_free(hT, wfd, mp[15]); };          // deferred group of an up stage
+        auto flush_downA = [&]() { mfma6_free(acc[7], wfd, hpA[1]); };   // ... of a down stage whose operand was hpA
+        auto flush_downB = [&]() { mfma6_free(acc[7], wfd, hpB[1]); };
+        stage_up(yes, none, flush_none);
+        flush_up();
 #pragma unroll
         for (int k = 0; k < 8; ++k) split_pair(k, hpA);
-#define PAIR(c)                                                                             \
-        stage_up(no, HEAD((c) - 1));                          /* chunk c */                  \
-        stage_down(hpA, hpB, yes, HEAD((c) - 1), ride0);      /* chunk c - 1, splits c */     \
-        stage_up(no, HEAD(c));                                /* chunk c + 1 */              \
-        stage_down(hpB, hpA, yes, HEAD(c), ride0);            /* chunk c, splits c + 1 */
-        PAIR(1) PAIR(3) PAIR(5) PAIR(7)
+#define PAIR(c, fl)                                                                         \
+        stage_up(no, HEAD((c) - 1), fl);                           /* chunk c */             \
+        stage_down(hpA, hpB, yes, HEAD((c) - 1), ride0, flush_up); /* chunk c - 1, splits c */ \
+        stage_up(no, HEAD(c), flush_downA);                        /* chunk c + 1 */         \
+        stage_down(hpB, hpA, yes, HEAD(c), ride0, flush_up);       /* chunk c, splits c + 1 */
+        PAIR(1, flush_none) PAIR(3, flush_downB) PAIR(5, flush_downB) PAIR(7, flush_downB)
 #undef PAIR
         for (int c = 9; c < 31; c += 2) {
-            stage_up(no, none);
-            stage_down(hpA, hpB, yes, none, ride0);
-            stage_up(no, none);
-            stage_down(hpB, hpA, yes, none, ride0);
+            stage_up(no, none, flush_downB);
+            stage_down(hpA, hpB, yes, none, ride0, flush_up);
+            stage_up(no, none, flush_downA);
+            stage_down(hpB, hpA, yes, none, ride0, flush_up);
         }
-        stage_up(no, none);                           // chunk 31
-        stage_down(hpA, hpB, yes, none, HEAD(1));      // chunk 30, splitting chunk 31; requests head 0 of the block's next tile
-        stage_down(hpB, hpA, no, none, HEAD(2));       // chunk 31; applies that head, requests head 1
+        stage_up(no, none, flush_downB);                           // chunk 31
+        stage_down(hpA, hpB, yes, none, HEAD(1), flush_up);         // chunk 30, splitting chunk 31; requests head 0 of the block's next tile
+        stage_down(hpB, hpA, no, none, HEAD(2), flush_downA);       // chunk 31; applies that head, requests head 1
+        flush_downB();                                              // norm2 needs the finished accumulators
 #undef HEAD
         // Drain: the ring's two stages in flight and head 1 of the next tile, requested two thirds of a stage ago.  That
         // head is applied here in the open (12 MFMAs), so that nothing pending lives across the norm2 block, and the y
