@@ -687,7 +687,7 @@ def test_tail_two_stream_soak_short():
     """tools/tail_soak.py for ~15 s: random row counts / cloud partitions of the fused layer tail on two streams at once
     (the lanes configuration), each draw against the unfused chain and twice for bitwise repeatability (the long runs are
     recorded in DESIGN.md: counted waits and a DMA ring are exactly what a once-in-10^5 race hides in)."""
-    import subprocess, sys
+    import os, subprocess, sys
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "tail_soak.py"), "15"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "tail soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
