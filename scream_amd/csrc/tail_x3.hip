@@ -390,12 +390,28 @@ constexpr int KV_PLANES_BYTES = 8 * 3 * 2 * 1024;            // per cloud: [head
 constexpr int KV_IMAGE_BYTES = KV_PLANES_BYTES + 8 * 32 * 4;  // + Ksum [head][32] fp32
 
 __device__ __forceinline__ void ld_asm(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p)); }
-// four loads 1 KiB apart from ONE address register (immediate offsets): the pieces a = 0 .. 3 of a fragment-major segment
-__device__ __forceinline__ void ld_asm4(f32x4 (&d)[4], const void* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d[0]) : "v"(p));
-    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(d[1]) : "v"(p));
-    asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(d[2]) : "v"(p));
-    asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(d[3]) : "v"(p));
+// Register loads address memory as (wave-uniform base in SGPRs) + (32-bit per-lane offset in ONE VGPR) + immediate: the
+// bases are scalar arithmetic, and no load needs a 64-bit VGPR address of its own (dozens of those, precomputed per tile
+// by hipcc, were what spilled at the tile boundaries).
+// four loads STEP bytes apart: the pieces a = 0 .. 3 of a fragment-major segment (1 KiB) or of a lane's 128-byte segment (32 B)
+template <int STEP>
+__device__ __forceinline__ void ld_asm4(f32x4 (&d)[4], const void* sbase, unsigned voff) {
+    static_assert(STEP == 1024 || STEP == 32, "");
+    if (STEP == 1024) {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d[0]) : "v"(voff), "s"(sbase));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(d[1]) : "v"(voff), "s"(sbase));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(d[2]) : "v"(voff), "s"(sbase));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(d[3]) : "v"(voff), "s"(sbase));
+    } else {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d[0]) : "v"(voff), "s"(sbase));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(d[1]) : "v"(voff), "s"(sbase));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(d[2]) : "v"(voff), "s"(sbase));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:96" : "=v"(d[3]) : "v"(voff), "s"(sbase));
+    }
+}
+__device__ __forceinline__ void ld_asm2k(f32x4& d0, f32x4& d1, const void* sbase, unsigned voff) {  // two loads 1 KiB apart
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d0) : "v"(voff), "s"(sbase));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(d1) : "v"(voff), "s"(sbase));
 }
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 
@@ -453,29 +469,24 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
     // of the NEXT stage, never kept pending across a LayerNorm block -- hipcc, which believes the value present, otherwise
     // spills it to scratch right behind the asm statement when registers are short there.
     // grp: first float of the wave's 32-row group (8192 floats in either layout); segment seg, piece a, this lane:
-    auto frag_ptr = [&](const float* base, int64_t grp, int seg, int a) { return base + grp + ((seg * 4 + a) * 64 + lane) * 4; };
+    const unsigned v_lane16 = lane * 16, v_half16 = half * 16;  // the only per-lane address parts
+    // the uniform part of the address of segment seg in the 32-row group starting at float `grp`
+    auto seg_base = [&](const float* base, int64_t grp, int seg) { return base + grp + seg * 1024; };
     auto req_q = [&](f32x4 (&qb)[4], int64_t grp, int h) {  // Q' of head h: the one operand that comes from HBM
         if (T_ABLATE & 16) return;
-        ld_asm4(qb, frag_ptr(Q, grp, h, 0));
+        ld_asm4<1024>(qb, seg_base(Q, grp, h), v_lane16);
     };
     auto req_head = [&](HeadOps& o, const char* kvc, int h) {  // KV^T fragments and Ksum of head h: L2-hot per-cloud data
         if (T_ABLATE & 16) return;
-        const char* kp = kvc + h * (3 * 2 * 1024) + lane * 16;
-        const float* sp = reinterpret_cast<const float*>(kvc + KV_PLANES_BYTES) + 32 * h + 4 * half;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(o.kv[0]) : "v"(kp));
-        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(o.kv[1]) : "v"(kp));
-        asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(o.kv[2]) : "v"(kp));
-        asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(o.kv[3]) : "v"(kp));
-        ld_asm(o.kv[4], kp + 4 * 1024);
-        ld_asm(o.kv[5], kp + 5 * 1024);
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(o.ks[0]) : "v"(sp));
-        asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(o.ks[1]) : "v"(sp));
-        asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(o.ks[2]) : "v"(sp));
-        asm volatile("global_load_dwordx4 %0, %1, off offset:96" : "=v"(o.ks[3]) : "v"(sp));
+        const char* kp = kvc + h * (3 * 2 * 1024);
+        f32x4 (&kv4)[4] = reinterpret_cast<f32x4 (&)[4]>(o.kv[0]);
+        ld_asm4<1024>(kv4, kp, v_lane16);
+        ld_asm2k(o.kv[4], o.kv[5], kp + 4 * 1024, v_lane16);
+        ld_asm4<32>(o.ks, kvc + KV_PLANES_BYTES + 128 * h, v_half16);
     };
     auto req_x = [&](f32x4 (&xs)[4], int64_t grp, int blk) {
         if (T_ABLATE & 16) return;
-        ld_asm4(xs, frag_ptr(xres, grp, blk, 0));
+        ld_asm4<1024>(xs, seg_base(xres, grp, blk), v_lane16);
     };
     auto pin_head = [&](HeadOps& o) {
 #pragma unroll
@@ -600,7 +611,9 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         // the block's next tile (its heads 0 and 1 are applied under / right after this tile's last stage)
         const int tile_next = tile + (int)gridDim.x;
         const bool has_next = tile_next < n_tiles;
-        const int64_t grp_next = ((int64_t)tile_next * 128 + wave * 32) * SCREAM_D_MODEL;
+        // (the last tile of a block "requests" its own operands again instead of branching around the requests: an asm load
+        // that is skipped on one path leaves the buffer's OLD contents live across the whole FFN phase -- 40 spilled registers)
+        const int64_t grp_next = ((int64_t)(has_next ? tile_next : tile) * 128 + wave * 32) * SCREAM_D_MODEL;
         const char* kvc_next = kvc;
         float S_next = 1.f;
         if (has_next) {
@@ -792,7 +805,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 pin_x(qA);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (RIDE == 1 && has_next) {
+            if (RIDE == 1) {
                 req_q(qA, grp_next, 0);
                 req_head(op, kvc_next, 0);
             }
@@ -813,10 +826,8 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 }
                 if (RIDE == 2 && g == 4) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (has_next) {  // head 1 into the buffers head 0 has just left (a second Q' buffer here, at the top of
-                        req_q(qA, grp_next, 1);  // the stage, was spilled by hipcc right behind its loads)
-                        req_head(op, kvc_next, 1);
-                    }
+                    req_q(qA, grp_next, 1);  // head 1 into the buffers head 0 has just left (a second Q' buffer here, at the
+                    req_head(op, kvc_next, 1);  // top of the stage, was spilled by hipcc right behind its loads)
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (RIDE == 2) {
@@ -897,7 +908,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             const float* gp = g2 + 4 * half;
             const float* bp = b2 + 4 * half;
             asm volatile("" : "+v"(gp), "+v"(bp));
-            float* yg = y + grp + lane * 4;
+            float* yg = y + grp + lane * 4;  // (uniform base + lane: the stores below differ by immediates and scalar adds)
 #pragma unroll
             for (int b = 0; b < 8; ++b)
 #pragma unroll
@@ -912,7 +923,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         }
         TSTAMP(5);  // tile end
         tile = tile_next;
-        grp = grp_next;
+        grp = ((int64_t)tile_next * 128 + wave * 32) * SCREAM_D_MODEL;
         kvc = kvc_next;
         S = S_next;
     }
