@@ -47,16 +47,28 @@
 // Diagnostic build only -- run tools/asm_inflight_check.py on it first: the extra registers can push hipcc into spilling
 // a pending load destination (it did, with one stamp per stage).
 #ifdef T_STAMPS
-__device__ long long t_stamps[256 * 4 * 8];
+#define T_STAMP_SLOTS 24  // 0-5: phase boundaries (64-bit s_memtime); 8-23: low words of the stamps taken at stage tops (TMARK)
+__device__ long long t_stamps[256 * 4 * T_STAMP_SLOTS];
 extern "C" int scream_tail_stamps_read(long long* host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(t_stamps), sizeof(long long) * 256 * 4 * 8);
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(t_stamps), sizeof(long long) * 256 * 4 * T_STAMP_SLOTS);
 }
 #define TSTAMP(slot)                                                                                 \
     do {                                                                                             \
-        if (stamp_on && lane == 0) t_stamps[((int)blockIdx.x * 4 + wave) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        if (stamp_on && lane == 0) t_stamps[((int)blockIdx.x * 4 + wave) * T_STAMP_SLOTS + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+// a stamp that stays in a scalar register until the tile's end: no memory instruction inside the stages
+#define TMARK(i) marks[i] = (unsigned)__builtin_amdgcn_s_memtime()
+#define TMARK2(i, prev) do { marks[prev] = marks[i]; TMARK(i); } while (0)
+#define TMARKS_FLUSH()                                                                               \
+    do {                                                                                             \
+        if (stamp_on && lane == 0)                                                                   \
+            for (int i_ = 0; i_ < 16; ++i_) t_stamps[((int)blockIdx.x * 4 + wave) * T_STAMP_SLOTS + 8 + i_] = marks[i_]; \
     } while (0)
 #else
 #define TSTAMP(slot) do {} while (0)
+#define TMARK(i) do {} while (0)
+#define TMARK2(i, prev) do {} while (0)
+#define TMARKS_FLUSH() do {} while (0)
 #endif
 
 namespace {
@@ -130,12 +142,21 @@ __device__ __forceinline__ bf16x8 ld_frag(const char* p) {
 
 // acc += W . act with both operands split in three bf16 planes: six exact products, smallest first
 // (W plane + activation plane <= 2), fp32 accumulate.  w = A operand (weights), a = B operand (activations).
-__device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&w)[3], const bf16x8 (&a)[3]) {
+// NV > 0: the stage carries VALU work of another computation (a "ride"); the scheduler is told to place up to NV of
+// those instructions behind every MFMA instead of leaving them in one run between two groups -- an MFMA occupies the
+// matrix pipe for 32 cycles, a VALU instruction issues in 4, so up to seven ride for free behind each.
+// zero: the accumulator tile starts here (first product takes the constant 0 as its C operand: no zeroing moves).
+template <int NV = 0>
+__device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&w)[3], const bf16x8 (&a)[3], bool zero = false) {
+    f32x16 z;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = 0.f;
     if (T_ABLATE & 2) {
+        if (zero) acc = z;
         acc[0] += (float)w[0][0] + (float)w[1][1] + (float)w[2][2] + (float)a[0][0] + (float)a[1][1] + (float)a[2][2];
         return;
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[2], zero ? z : acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], a[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], a[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[1], acc, 0, 0, 0);
@@ -144,7 +165,16 @@ __device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&w)[3], const b
     // first MFMA, then the three prefetch reads of the next fragment group, then the other five MFMAs
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+    if (NV == 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -425,17 +455,33 @@ struct HeadOps {   // the per-cloud operands of one head's apply, as loaded (Q' 
 #define LGKM_WAIT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // acc += W . act, plain (no scheduling directives): for the short products that ride inside another stage's groups
-__device__ __forceinline__ void mfma6_free(f32x16& acc, const bf16x8 (&w)[3], const bf16x8 (&a)[3]) {
+__device__ __forceinline__ void mfma6_free(f32x16& acc, const bf16x8 (&w)[3], const bf16x8 (&a)[3], bool zero = false) {
+    f32x16 z;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = 0.f;
     if (T_ABLATE & 2) {
+        if (zero) acc = z;
         acc[0] += (float)w[0][0] + (float)a[0][0];
         return;
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[2], zero ? z : acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], a[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], a[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], a[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], a[0], acc, 0, 0, 0);
+}
+
+// merge stage h (h >= 1): which quarter of the x-segment add rides in group g (-1: none) -- the last four groups of
+// 14 .. 8 that do not accumulate into tile h - 1
+__device__ __forceinline__ constexpr int xadd_slot(int h, int g) {
+    int n = 0;
+    for (int c = 14; c >= 8; --c) {
+        if ((c >> 1) == h - 1) continue;
+        if (c == g) return n < 4 ? n : -1;
+        ++n;
+    }
+    return -1;
 }
 
 __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict__ Q,      // fragment-major [M, 256]
@@ -448,15 +494,27 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                                                         const float* __restrict__ g2, const float* __restrict__ b2,
                                                         float* __restrict__ y,            // fragment-major [M, 256]
                                                         int n_tiles) {
-    __shared__ __attribute__((aligned(16))) char smem[T_SLOTS * T_STAGE];  // 144 KiB, the ONLY LDS object
+    __shared__ __attribute__((aligned(16))) char smem[T_SLOTS * T_STAGE + 4096];  // 144 KiB ring + the norm parameters, the ONLY LDS object
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
-    const char* w_lane = reinterpret_cast<const char*>(Wimg) + lane * 16;
+    // gamma1 | beta1 | gamma2 | beta2 live in LDS for the whole launch.  Read from global memory inside the norm blocks they
+    // cost more than the arithmetic: on gfx950 loads and stores share vmcnt, hipcc cannot order a load against the y stores
+    // issued before it and waits with vmcnt(0) -- a full store round trip per group of rows (tools/tail_stamps.py: 11.8 k
+    // cycles for norm2 + stores).  From LDS the y stores are fire-and-forget.
+    float* lnp = reinterpret_cast<float*>(smem + T_SLOTS * T_STAGE);
+    lnp[tid] = g1[tid];
+    lnp[256 + tid] = b1[tid];
+    lnp[512 + tid] = g2[tid];
+    lnp[768 + tid] = b2[tid];
+    const unsigned v_lane16 = lane * 16, v_half16 = half * 16;  // the only per-lane address parts of the kernel
+    // weight pieces: uniform (scalar) source address + the 32-bit lane offset.  A per-lane 64-bit pointer kept across the
+    // kernel was spilled by hipcc and reloaded from scratch in EVERY stage -- behind a vmcnt(0) that drained the ring.
     auto dma_piece = [&](unsigned q, int u) {
         if ((T_ABLATE & 1) && q >= 2) return;
         const unsigned src = q % (unsigned)TAIL_STAGES, slot = q % (unsigned)T_SLOTS;
-        dma_1k(w_lane + (size_t)src * T_STAGE + (wave * 12 + (u & ~3)) * 1024, smem + slot * T_STAGE + (wave * 12 + (u & ~3)) * 1024, u & 3);
+        const char* sbase = reinterpret_cast<const char*>(Wimg) + (size_t)src * T_STAGE + (wave * 12 + (u & ~3)) * 1024;
+        dma_1k(sbase + v_lane16, smem + slot * T_STAGE + (wave * 12 + (u & ~3)) * 1024, u & 3);
     };
     unsigned q = 0;  // next stage to be consumed
 #pragma unroll
@@ -469,15 +527,14 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
     // of the NEXT stage, never kept pending across a LayerNorm block -- hipcc, which believes the value present, otherwise
     // spills it to scratch right behind the asm statement when registers are short there.
     // grp: first float of the wave's 32-row group (8192 floats in either layout); segment seg, piece a, this lane:
-    const unsigned v_lane16 = lane * 16, v_half16 = half * 16;  // the only per-lane address parts
     // the uniform part of the address of segment seg in the 32-row group starting at float `grp`
     auto seg_base = [&](const float* base, int64_t grp, int seg) { return base + grp + seg * 1024; };
     auto req_q = [&](f32x4 (&qb)[4], int64_t grp, int h) {  // Q' of head h: the one operand that comes from HBM
-        if (T_ABLATE & 16) return;
+        if (T_ABLATE & (16 | 32)) return;
         ld_asm4<1024>(qb, seg_base(Q, grp, h), v_lane16);
     };
     auto req_head = [&](HeadOps& o, const char* kvc, int h) {  // KV^T fragments and Ksum of head h: L2-hot per-cloud data
-        if (T_ABLATE & 16) return;
+        if (T_ABLATE & (16 | 256)) return;
         const char* kp = kvc + h * (3 * 2 * 1024);
         f32x4 (&kv4)[4] = reinterpret_cast<f32x4 (&)[4]>(o.kv[0]);
         ld_asm4<1024>(kv4, kp, v_lane16);
@@ -485,7 +542,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         ld_asm4<32>(o.ks, kvc + KV_PLANES_BYTES + 128 * h, v_half16);
     };
     auto req_x = [&](f32x4 (&xs)[4], int64_t grp, int blk) {
-        if (T_ABLATE & 16) return;
+        if (T_ABLATE & (16 | 64)) return;
         ld_asm4<1024>(xs, seg_base(xres, grp, blk), v_lane16);
     };
     auto pin_head = [&](HeadOps& o) {
@@ -493,6 +550,10 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         for (int a = 0; a < 4; ++a) pin(o.ks[a]);
 #pragma unroll
         for (int f = 0; f < 6; ++f) pin(o.kv[f]);
+    };
+    auto add_x4 = [&](f32x16& t, const f32x4 (&xs)[4], int a) {  // one quarter (registers 4a .. 4a + 3)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[4 * a + k] += (T_ABLATE & 16) ? 1.0f : xs[a][k];
     };
     auto pin_x = [&](f32x4 (&xs)[4]) {
 #pragma unroll
@@ -518,25 +579,19 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
     float Zs = 0.f;
 
     // ---- apply of one head (models/transformer.py:41-42), in pieces that ride inside the groups of another stage ----
-    auto apply_qsplit = [&](f32x4 (&qb)[4], int tile_tag) {
+    auto apply_qsplit = [&](f32x4 (&qb)[4], int tile_tag, int s2) {  // 16-deep step s2 of Q' into its three planes
         if (T_ABLATE & 16) {
             const f32x4 f = {(float)lane, 1.0f, 0.5f, (float)tile_tag};
-            split3(f, f, qp[0][0], qp[0][1], qp[0][2]);
-            split3(f, f, qp[1][0], qp[1][1], qp[1][2]);
+            split3(f, f, qp[s2][0], qp[s2][1], qp[s2][2]);
             return;
         }
-        split3(qb[0], qb[1], qp[0][0], qp[0][1], qp[0][2]);
-        split3(qb[2], qb[3], qp[1][0], qp[1][1], qp[1][2]);
+        split3(qb[2 * s2], qb[2 * s2 + 1], qp[s2][0], qp[s2][1], qp[s2][2]);
     };
     auto apply_mfma = [&](int s2) {
         bf16x8 w[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) w[p] = __builtin_bit_cast(bf16x8, op.kv[p * 2 + s2]);
-        if (s2 == 0) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) aT[e] = 0.f;
-        }
-        mfma6_free(aT, w, qp[s2]);
+        mfma6_free(aT, w, qp[s2], s2 == 0);
     };
     auto apply_z = [&](f32x4 (&qb)[4]) {  // Z = 1 / (Q'.Ksum + 1e-6); lanes r and r + 32 share row r
         float zp = 0.f;
@@ -562,7 +617,8 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
     };
     // the pieces of one apply as they ride in group g of a 16-group stage: operands consumed in groups 0-3
     auto apply_ride = [&](f32x4 (&qb)[4], int g, bf16x8 (&ap)[2][3], float S, int tile_tag) {
-        if (g == 0) apply_qsplit(qb, tile_tag);
+        if (g == 0) apply_qsplit(qb, tile_tag, 0);
+        if (g == 1) apply_qsplit(qb, tile_tag, 1);
         if (g == 1) apply_mfma(0);
         if (g == 2) apply_mfma(1);
         if (g == 3) apply_z(qb);
@@ -597,17 +653,16 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         const bool stamp_on = tile_no == 1;
         ++tile_no;
 #endif
+#ifdef T_STAMPS
+        unsigned marks[16] = {};
+#endif
         TSTAMP(0);  // tile start
         // The last MFMA group of every stage is DEFERRED across the barrier: its weight fragments are read into wfd, and
         // the next stage issues it right after the first fragment reads of its own -- 6 MFMAs (192 cycles) of work with
         // register operands exactly where a lone in-order wave otherwise waits for the LDS (tools/tail_stamps.py: 3.8 k
         // cycles per 3.07 k-cycle stage).  `flush` arguments below name the deferred group of the preceding stage.
         bf16x8 wfd[3];
-        f32x16 acc[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
+        f32x16 acc[8];  // (started by the first product of merge stage 0 / of the first down stage: no zeroing moves)
         // the block's next tile (its heads 0 and 1 are applied under / right after this tile's last stage)
         const int tile_next = tile + (int)gridDim.x;
         const bool has_next = tile_next < n_tiles;
@@ -635,22 +690,19 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             // stage 0 of a tile: everything older was drained at the end of the previous tile (only its y stores may
             // still be in flight, and nothing of this stage depends on them)
             if (h == 0) lds_only_barrier(); else ring_barrier<12>();
+            TMARK(h);  // T_STAMPS builds: marks 0-7 = the tops of the merge stages
             __builtin_amdgcn_sched_barrier(0);
+            f32x4 (&x_prev)[4] = (h & 1) ? xs : xs2;   // segment h - 1 (landed: requested by stage h - 1)
+            f32x4 (&x_req)[4] = (h & 1) ? xs2 : xs;    // segment h
             if (h > 0) {
-                pin_x(xs);
-                add_x(acc[h > 0 ? h - 1 : 0], xs);
+                pin_x(x_prev);
                 if (RIDE) {
                     pin_head(op);
                     pin_x(q_cons);
                 }
             }
-            if (h == 7) {
-                pin_x(xs2);
-                add_x(acc[7], xs2);
-            }
             __builtin_amdgcn_sched_barrier(0);
-            if (h < 7) req_x(xs, grp, h);
-            if (h == 6) req_x(xs2, grp, 7);
+            req_x(x_req, grp, h);
             if (h + 2 < 8) req_q(q_req, grp, h + 2);  // consumed by stage h + 1
             if (h == 0) req_head(op, kvc, 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -675,8 +727,14 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 }
                 if (g >= 4) dma_piece(q + 2, g - 4);
                 if (g == 14) dma_piece(q + 2, 11);  // (group 15 is deferred: the twelfth piece goes out with the eleventh)
-                if (RIDE) apply_ride(q_cons, g, ap_next, S, tile);
-                mfma6(acc[g >> 1], wf[g % T_PF], ap[g & 1]);
+                if (RIDE && !(T_ABLATE & 512)) apply_ride(q_cons, g, ap_next, S, tile);
+                // the norm1 residual: segment h - 1 joins accumulator tile h - 1 in quarters, in late groups that do not
+                // accumulate into that tile (its MFMAs are groups 2h - 2 and 2h - 1)
+                if (h > 0) {
+                    const int pc = xadd_slot(h, g);
+                    if (pc >= 0 && !(T_ABLATE & 1024)) add_x4(acc[h > 0 ? h - 1 : 0], x_prev, pc);
+                }
+                mfma6<(h > 0 ? 6 : 0)>(acc[g >> 1], wf[g % T_PF], ap[g & 1], h == 0 && (g & 1) == 0);
             }
             ++q;
         };
@@ -696,6 +754,9 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         stage_merge(HEAD(6), apA, apB, qB, qA, flush_mergeB);
         stage_merge(HEAD(7), apB, apA, qA, qB, flush_mergeA);
         flush_mergeB();  // norm1 needs the finished accumulators
+        VM_WAIT(12);     // x segment 7 (requested at the top of stage 7, older than that stage's twelve weight pieces)
+        pin_x(xs2);
+        add_x(acc[7], xs2);
 
         TSTAMP(1);  // end of the merge phase
         // ---- m1 = LayerNorm1(merge + x) (models/transformer.py:84), straight into the B-operand planes of FFN-up ---
@@ -718,9 +779,8 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 }
             var += __shfl_xor(var, 32);
             const float rstd = 1.0f / sqrtf(var * (1.0f / 256.0f) + 1e-5f);
-            const float* gp = g1 + 4 * half;
-            const float* bp = b1 + 4 * half;
-            asm volatile("" : "+v"(gp), "+v"(bp));  // not hoisted out of the tile loop (see ffn_x3_kernel)
+            const float* gp = lnp + 4 * half;
+            const float* bp = lnp + 256 + 4 * half;
 #pragma unroll
             for (int b = 0; b < 8; ++b)
 #pragma unroll
@@ -735,10 +795,6 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                     }
                     split3(v[0], v[1], mp[2 * b + s2][0], mp[2 * b + s2][1], mp[2 * b + s2][2]);
                 }
-#pragma unroll
-            for (int b = 0; b < 8; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;
         }
 
         TSTAMP(2);  // end of norm1
@@ -763,6 +819,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             constexpr int XLOAD = decltype(xload)::value;
             // FIRST: the norm1 block above used ordinary loads (gamma, beta), which hipcc waits for with vmcnt(0)
             if (decltype(first)::value) ring_barrier<0>(); else ring_barrier<12>();
+            TMARK2(8, 10);  // T_STAMPS builds: tops of the last two up stages
             __builtin_amdgcn_sched_barrier(0);
             if (XLOAD >= 0) req_x(xs, grp, XLOAD);
             __builtin_amdgcn_sched_barrier(0);
@@ -774,8 +831,6 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 for (int p = 0; p < 3; ++p) wf[g0][p] = ld_frag(wb + (p * 16 + g0) * 1024);
             flush();
 #pragma unroll
-            for (int e = 0; e < 16; ++e) hT[e] = 0.f;
-#pragma unroll
             for (int g = 0; g < 15; ++g) {  // group 15 (hT += wfd . mp[15]) is deferred to the next stage
                 if (g + T_PF - 1 < 16) {
 #pragma unroll
@@ -783,7 +838,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                         (g + T_PF - 1 == 15 ? wfd[p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag(wb + (p * 16 + g + T_PF - 1) * 1024);
                 }
                 if (g < 12) dma_piece(q + 2, g);
-                mfma6(hT, wf[g % T_PF], mp[g]);
+                mfma6(hT, wf[g % T_PF], mp[g], g == 0);
             }
             ++q;
         };
@@ -795,10 +850,17 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             constexpr int XADD = decltype(xadd)::value;
             constexpr int RIDE = decltype(ride)::value;
             ring_barrier<12>();
+            TMARK2(9, 11);  // ... and of the last two down stages
             __builtin_amdgcn_sched_barrier(0);
-            if (XADD >= 0) {
+            if (XADD == 0) {  // the tile's first down stage starts the accumulators: tile 0 from its x segment, the others from 0
                 pin_x(xs);
-                add_x(acc[XADD >= 0 ? XADD : 0], xs);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[0][4 * a + k] = (T_ABLATE & 16) ? 1.0f : xs[a][k];
+            } else if (XADD > 0) {
+                pin_x(xs);
+                add_x(acc[XADD > 0 ? XADD : 0], xs);
             }
             if (RIDE == 2) {  // (untouched registers when the block has no next tile: the results are never used)
                 pin_head(op);
@@ -838,7 +900,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 }
                 if (RIDE == 2) apply_ride(qA, g, apA, S_next, tile_next);
                 if (decltype(with_split)::value && (g & 1) == 0) split_pair(g >> 1, hout);
-                mfma6(acc[g >> 1], wf[g % T_PF], hin[g & 1]);
+                mfma6(acc[g >> 1], wf[g % T_PF], hin[g & 1], XADD == 0 && g >= 2 && (g & 1) == 0);
             }
             ++q;
         };
@@ -905,9 +967,8 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 }
             var += __shfl_xor(var, 32);
             const float rstd = 1.0f / sqrtf(var * (1.0f / 256.0f) + 1e-5f);
-            const float* gp = g2 + 4 * half;
-            const float* bp = b2 + 4 * half;
-            asm volatile("" : "+v"(gp), "+v"(bp));
+            const float* gp = lnp + 512 + 4 * half;
+            const float* bp = lnp + 768 + 4 * half;
             float* yg = y + grp + lane * 4;  // (uniform base + lane: the stores below differ by immediates and scalar adds)
 #pragma unroll
             for (int b = 0; b < 8; ++b)
@@ -918,10 +979,11 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
 #pragma unroll
                     for (int k = 0; k < 4; ++k) o[k] = acc[b][4 * a + k] * rstd * g4[k] + b4[k];
                     // one contiguous 1 KiB per wave instruction
-                    if (!(T_ABLATE & 16) || o[0] + o[1] + o[2] + o[3] == 123.456f) *reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256) = o;
+                    if (!(T_ABLATE & (16 | 128)) || o[0] + o[1] + o[2] + o[3] == 123.456f) *reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256) = o;
                 }
         }
         TSTAMP(5);  // tile end
+        TMARKS_FLUSH();
         tile = tile_next;
         grp = ((int64_t)tile_next * 128 + wave * 32) * SCREAM_D_MODEL;
         kvc = kvc_next;

@@ -5,7 +5,8 @@ samples socket power and sclk (`run`, on the GPU).  The two-launch FFN of gemm_x
 import ctypes, os, re, subprocess, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tools", "_tabl" + os.environ.get("T_TAG", ""))
-VARIANTS = [(0, "full"), (1, "no W DMA"), (16, "no row I/O"), (8, "no relu/split"), (4, "no LDS reads"), (1 | 4, "no DMA, no LDS reads"),
+VARIANTS = [(0, "full"), (1, "no W DMA"), (16, "no row I/O"), (32, "no Q' loads"), (64, "no x loads"), (128, "no y stores"),
+            (256, "no KV^T / Ksum loads"), (8, "no relu/split"), (4, "no LDS reads"), (1 | 4, "no DMA, no LDS reads"),
             (2, "no MFMA"), (1 | 4 | 8 | 16, "MFMA only")]
 if os.environ.get("T_VARIANTS"):
     VARIANTS = [v for v in VARIANTS if str(v[0]) in os.environ["T_VARIANTS"].split(",")]

@@ -4,7 +4,7 @@ library has none).  `build` on the CPU box, `run` on the GPU: stamps of the seco
 blocks and waves, after a second of back-to-back launches so that the clock has settled."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SO = os.path.join(ROOT, "tools", "_tabl", "t_stamps.so")
+SO = os.path.join(ROOT, "tools", "_tabl", "t_stamps%s.so" % os.environ.get("T_TAG", ""))
 
 
 def build():
@@ -48,9 +48,10 @@ def run():
     while time.time() - t0 < 1.5:
         for _ in range(10): assert call() == 0
         torch.cuda.synchronize()
-    buf = (ctypes.c_longlong * (256 * 4 * 96))()
+    SLOTS = 24
+    buf = (ctypes.c_longlong * (256 * 4 * SLOTS))()
     assert lib.scream_tail_stamps_read(buf) == 0
-    a = np.frombuffer(buf, dtype=np.int64).reshape(256 * 4, 96)
+    a = np.frombuffer(buf, dtype=np.int64).reshape(256 * 4, SLOTS)
     a = a[a[:, 5] > 0]
     d = np.diff(a[:, :6], axis=1)
     med = np.median(d, axis=0)
@@ -60,6 +61,21 @@ def run():
     print("waves with stamps: %d; tile total median %d cycles (MFMA floor 72 x 3072 + 8 x 384 = 224256)" % (a.shape[0], tot))
     for nm, v in zip(names, med):
         print("  %-58s %8d  %5.1f %%" % (nm, v, 100.0 * v / tot))
+    # stage tops inside the merge phase (low 32 bits of s_memtime, kept in scalar registers until the tile's end)
+    m = a[:, 8:16] & 0xFFFFFFFF
+    t0 = a[:, 0] & 0xFFFFFFFF
+    t1 = a[:, 1] & 0xFFFFFFFF
+    edges = np.concatenate([m, t1[:, None]], axis=1)
+    dm = (np.diff(edges, axis=1)) & 0xFFFFFFFF
+    print("  merge stages (top to top; the last one to the end of the phase): " + " ".join("%d" % v for v in np.median(dm, axis=0)))
+    print("  tile start to the top of merge stage 0: %d" % np.median((m[:, 0] - t0) & 0xFFFFFFFF))
+    # FFN: marks 10, 8 = tops of up(30), up(31); 11, 9 = tops of down(30), down(31).  Order: up30 down29 up31 down30 down31
+    f = a[:, 16:20] & 0xFFFFFFFF  # marks 8, 9, 10, 11
+    pair = (f[:, 0] - f[:, 2]) & 0xFFFFFFFF
+    up = (f[:, 3] - f[:, 0]) & 0xFFFFFFFF
+    dn30 = (f[:, 1] - f[:, 3]) & 0xFFFFFFFF
+    print("  FFN: up stage %d, down stage %d (up + down pair %d); down(30), which also requests the next tile's head 0: %d"
+          % (np.median(up), np.median(pair - up), np.median(pair), np.median(dn30)))
 
 
 if __name__ == "__main__":
