@@ -26,6 +26,7 @@ SOURCES = {
     "nn_search.hip": ["-ffp-contract=off"],
     "kabsch.hip": ["-ffp-contract=off"],
 }
+ASM_LOADS = ("gemm_x3.hip", "tail_x3.hip")  # verified after code generation, see verify_one
 
 
 def _hipcc() -> str:
@@ -62,8 +63,31 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(r.stderr, file=sys.stderr)
         return obj
 
+    def verify_one(src):
+        """The files in ASM_LOADS request operands with inline asm and wait for them with hand-counted s_waitcnt vmcnt(N);
+        whether hipcc's register allocation respects that is a property of the generated code, not of the source.  So the
+        build proves it on the very code it ships (same flags, assembly instead of an object): tools/asm_inflight_check.py
+        walks every kernel and the build FAILS if any instruction touches a register whose load is still outstanding."""
+        sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+        import asm_inflight_check as chk
+        asm = os.path.join(objdir, src.replace(".hip", ".s"))
+        cmd = common + SOURCES[src] + ["-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", asm]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc -S failed for %s:\n%s" % (src, r.stderr))
+        for name, body in chk.kernels(asm):
+            bad = chk.check_kernel(name, body)
+            if bad:
+                raise RuntimeError("%s: %s touches a register whose asm load is still in flight (%d places, first: %s); "
+                                   "this hipcc allocates registers differently from the one the kernels were written with"
+                                   % (src, name, len(bad), bad[0][1]))
+        return src
+
     with ThreadPoolExecutor(max_workers=4) as ex:
+        checks = [ex.submit(verify_one, src) for src in ASM_LOADS] if os.environ.get("SCREAM_BUILD_VERIFY", "1") != "0" else []
         objs = list(ex.map(compile_one, SOURCES.items()))
+        for c in checks:
+            c.result()
     cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
