@@ -155,6 +155,24 @@ int scream_layer_tail_x3_f32(const float* Q, const void* kv_image, const int32_t
                              const void* tail_image, const float* g1, const float* b1, const float* g2,
                              const float* b2, float* y, int64_t M, void* stream);
 
+/* ---- A2 + the reduce half of A3 in the geometry of the layer tail: the q / k / v projections of a block
+ * (models/transformer.py:27-36: q_proj, k_proj, v_proj, elu + 1 on q and k) with the fused K^T V reduction (:38-41).
+ * Same results as scream_gemm_qkv_x3_ex_f32 to rounding, fewer joules per row (scream_amd/csrc/proj_x3.hip): the bf16
+ * planes of the input rows are made once per 128-row tile for all 24 output chunks, Q' leaves the accumulators in the
+ * fragment-major layout without an LDS round trip, K'^T V is reduced by bf16 MFMAs straight from the split accumulators.
+ *   proj_image: scream_pack_proj_x3(Wq, Wk, Wv) -- q_proj / k_proj / v_proj .weight, [256,256] fp32 each, device to device;
+ *               8 query stages then 16 key/value stages of 48 KiB (scream_proj_image_bytes(1, 1) bytes).  Wq == NULL or
+ *               Wk == Wv == NULL packs only the other part.  A full image serves all three modes: has_q only reads its
+ *               first 8 stages, has_kv only takes the pointer image + scream_proj_image_bytes(1, 0).
+ *   x [M,256] FRAGMENT-major fp32, M % 128 == 0;  has_q: Q [M,256] FRAGMENT-major = elu(x Wq^T) + 1;
+ *   has_kv: kv_partial [M/128][8][33*32] as scream_gemm_qkv_f32 writes it (tile_cloud / cloud_row0 / cloud_len / row_base
+ *   with the same meaning: row 0 of x is packed row row_base; padding rows are excluded from the sums). */
+int64_t scream_proj_image_bytes(int32_t has_q, int32_t has_kv);
+int scream_pack_proj_x3(const float* Wq, const float* Wk, const float* Wv, void* proj_image, void* stream);
+int scream_proj_x3_f32(const float* x, const void* proj_image, int32_t has_q, int32_t has_kv, float* Q,
+                       float* kv_partial, const int32_t* tile_cloud, const int32_t* cloud_row0,
+                       const int32_t* cloud_len, int64_t row_base, int64_t M, void* stream);
+
 /* ---- A1: feats = LayerNorm(PE_sine(xyz) + W_e (xyz - center[cloud]) + b_e)
  * Replaces models/pointnet.py:45-48 (+ models/transformer.py:157-179).  xyz [rows,3] packed;
  * tile_cloud[rows/128] gives the cloud of each 128-row tile; center [n_clouds,3] (zeros for
@@ -206,6 +224,9 @@ typedef struct {
      * apply, merge + norm1 and the FFN + norm2 as ONE launch per block (scream_layer_tail_x3_f32) and ignores wm, w1, w2
      * and ffn. */
     const void* tail;
+    /* tail != NULL only; may be NULL.  scream_pack_proj_x3 image of (q_proj, k_proj, v_proj): the forward then runs the
+     * projections on scream_proj_x3_f32 and ignores wqkv / wq / wkv. */
+    const void* proj;
 } scream_layer_t;
 
 typedef struct {

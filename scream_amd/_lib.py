@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscream_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -21,7 +21,7 @@ c_u64p = C.POINTER(C.c_uint64)
 
 
 class LayerT(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "wq", "wkv", "wm", "w1", "w2", "g1", "b1", "g2", "b2", "ffn", "tail")]
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "wq", "wkv", "wm", "w1", "w2", "g1", "b1", "g2", "b2", "ffn", "tail", "proj")]
 
 
 class ModelT(C.Structure):
@@ -58,6 +58,9 @@ SIGNATURES = {
     "scream_kv_finalize_x3": (C.c_int, [V, V, V, I64, I32, I32, V, V]),
     "scream_layer_tail_x3_f32": (C.c_int, [V, V, V, I32, V, V, V, V, V, V, V, V, I64, V]),
     "scream_act_layout": (C.c_int, [V, V, I64, I32, V]),
+    "scream_proj_image_bytes": (I64, [I32, I32]),
+    "scream_pack_proj_x3": (C.c_int, [V, V, V, V, V]),
+    "scream_proj_x3_f32": (C.c_int, [V, V, I32, I32, V, V, V, V, V, I64, I64, V]),
     "scream_gemm_x3_ex_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, I32, V, V, I64, V, V, I32, V]),
     "scream_gemm_qkv_x3_ex_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, V, V, V, I64, V, I32, V]),
     "scream_pe_embed_ln": (C.c_int, [V, V, V, V, V, V, V, V, V, I64, V]),

@@ -20,13 +20,14 @@ SOURCES = {
     # several code instances of the same arithmetic (an attention apply in the open / riding under another stage) must round
     # identically, whatever hipcc makes of each: no fma contraction in this file
     "tail_x3.hip": ["-ffp-contract=off"],
+    "proj_x3.hip": ["-ffp-contract=off"],
     "embed.hip": [],
     "attention.hip": [],
     "forward.hip": [],
     "nn_search.hip": ["-ffp-contract=off"],
     "kabsch.hip": ["-ffp-contract=off"],
 }
-ASM_LOADS = ("gemm_x3.hip", "tail_x3.hip")  # verified after code generation, see verify_one
+ASM_LOADS = ("gemm_x3.hip", "tail_x3.hip", "proj_x3.hip")  # verified after code generation, see verify_one
 
 
 def _hipcc() -> str:
@@ -81,6 +82,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 raise RuntimeError("%s: %s touches a register whose asm load is still in flight (%d places, first: %s); "
                                    "this hipcc allocates registers differently from the one the kernels were written with"
                                    % (src, name, len(bad), bad[0][1]))
+            sd = chk.check_store_data_hazard(name, body)
+            if sd:
+                raise RuntimeError("%s: %s overwrites the data of a wide store %d wait states behind it (%s ; %s)"
+                                   % (src, name, sd[0][3], sd[0][1], sd[0][2]))
+            hz = chk.check_scalar_base_hazard(name, body)
+            if hz:
+                raise RuntimeError("%s: %s uses a scalar base %d wait states after a VALU write of it (%s -> %s)"
+                                   % (src, name, hz[0][3], hz[0][2], hz[0][1]))
         return src
 
     with ThreadPoolExecutor(max_workers=4) as ex:

@@ -92,9 +92,12 @@ int gemm(const Ctx& c, const float* A, int64_t lda, const float* W, float* C, in
     return scream_gemm_f32(A, lda, W, C, ldc, M, N, K, epi, n_act, bias, res, D, g, b, c.st);
 }
 
-int gemm_qkv(const Ctx& c, const float* A, const float* W, float* Q, int64_t M, int N, int n_q, const scream_batch_t& b,
-             int64_t row_base, float* kvp) {
+int gemm_qkv(const Ctx& c, const float* A, const float* W, const void* proj, float* Q, int64_t M, int N, int n_q,
+             const scream_batch_t& b, int64_t row_base, float* kvp) {
     Scope sc(c.tr, 5, M, N, D, c.st);
+    if (c.frag && proj)  // ring-design projection kernel (proj_x3.hip); the image holds 8 query stages, then 16 key/value stages
+        return scream_proj_x3_f32(A, n_q ? proj : static_cast<const char*>(proj) + scream_proj_image_bytes(1, 0), n_q != 0, 1, Q, kvp,
+                                  b.tile_cloud, b.cloud_row0, b.cloud_len, row_base, M, c.st);
     if (c.planes)
         return scream_gemm_qkv_x3_ex_f32(A, D, W, Q, D, M, N, D, n_q, b.tile_cloud, b.cloud_row0, b.cloud_len, row_base, kvp,
                                          c.frag ? (SCREAM_LAYOUT_A_FRAG | (n_q ? SCREAM_LAYOUT_C_FRAG : 0)) : 0, c.st);
@@ -126,7 +129,7 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
     const float* xr = x + row0 * D;
     float* qr = w.q + row0 * D;
     float* kvp = w.kvp + row0 / SCREAM_ROW_TILE * SCREAM_NHEAD * KV_ELEMS;
-    TRY(gemm_qkv(c, xr, L.wqkv, qr, rows, 3 * D, D, b, row0, kvp));
+    TRY(gemm_qkv(c, xr, L.wqkv, L.proj, qr, rows, 3 * D, D, b, row0, kvp));
     if (c.frag) {  // apply + merge + norm1 + FFN + norm2 in one launch
         {
             Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
@@ -152,9 +155,14 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
 int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x_src,
               const float* x_tgt, float* y) {
     const int64_t rs = b.rows_src, rt = b.rows_total - b.rows_src;
-    TRY(gemm(c, x_src, D, L.wq, w.q, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr,
-             c.frag ? (SCREAM_LAYOUT_A_FRAG | SCREAM_LAYOUT_C_FRAG) : 0));
-    TRY(gemm_qkv(c, x_tgt, L.wkv, nullptr, rt, 2 * D, 0, b, rs, w.kvp));
+    if (c.frag && L.proj) {
+        Scope sc(c.tr, SCREAM_EPI_ELU1, rs, D, D, c.st);
+        TRY(scream_proj_x3_f32(x_src, L.proj, 1, 0, w.q, nullptr, nullptr, nullptr, nullptr, 0, rs, c.st));
+    } else {
+        TRY(gemm(c, x_src, D, L.wq, w.q, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr,
+                 c.frag ? (SCREAM_LAYOUT_A_FRAG | SCREAM_LAYOUT_C_FRAG) : 0));
+    }
+    TRY(gemm_qkv(c, x_tgt, L.wkv, L.proj, nullptr, rt, 2 * D, 0, b, rs, w.kvp));
     if (c.frag) {
         {
             Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
@@ -177,8 +185,8 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
 
 }  // namespace
 
-extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi9"; }
-extern "C" int scream_abi_version(void) { return 9; }
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi10"; }
+extern "C" int scream_abi_version(void) { return 10; }
 
 extern "C" void* scream_trace_create(int32_t capacity) {
     if (capacity <= 0) return nullptr;

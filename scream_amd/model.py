@@ -99,9 +99,13 @@ class PointTransformer(nn.Module):
     # x3 only: attention apply, merge + LayerNorm1 and the FFN + LayerNorm2 as one launch per block; SCREAM_FUSED_TAIL=0
     # falls back to attn_apply + merge GEMM + (fused or two-launch) FFN
     fused_tail = os.environ.get("SCREAM_FUSED_TAIL", "1") != "0"
+    # fused tail only, OFF by default: the q/k/v projections on the ring-design kernel (csrc/proj_x3.hip) instead of the 8-wave
+    # split GEMM.  Same results to rounding; measured 0.6-1 % slower per step (its 128-row work items quantise worse over the
+    # 256 CUs and its elu / split rides do not hide under the MFMAs of a lone wave).  SCREAM_RING_PROJ=1.
+    ring_proj = os.environ.get("SCREAM_RING_PROJ", "0") != "0"
 
     def _signature(self):
-        return (self.gemm_backend, self.fused_ffn, self.fused_tail) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.gemm_backend, self.fused_ffn, self.fused_tail, self.ring_proj) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _pack_weights(self):
         sig = self._signature()
@@ -147,6 +151,11 @@ class PointTransformer(nn.Module):
                 img = ops.pack_tail(f32(m.merge.weight), f32(m.mlp[0].weight), f32(m.mlp[2].weight))
                 keep.append(img)
                 L.tail = img.data_ptr()
+            L.proj = None
+            if L.tail is not None and self.ring_proj:
+                img = ops.pack_proj(m.q_proj.weight.to(dev), m.k_proj.weight.to(dev), m.v_proj.weight.to(dev))
+                keep.append(img)
+                L.proj = img.data_ptr()
             L.wm = dev_mat(m.merge.weight)
             if L.tail is not None:
                 L.ffn, L.w1, L.w2 = None, None, None

@@ -151,6 +151,33 @@ def layer_tail(Q: torch.Tensor, kv_image: torch.Tensor, tile_cloud, kv_cloud_off
     return out
 
 
+def pack_proj(Wq: Optional[torch.Tensor], Wk: Optional[torch.Tensor], Wv: Optional[torch.Tensor]) -> torch.Tensor:
+    """q_proj / k_proj / v_proj .weight ([256,256] each; Wq or the pair Wk, Wv may be None) -> the weight image of proj_x3."""
+    ws = [None if w is None else w.detach().to(torch.float32).contiguous() for w in (Wq, Wk, Wv)]
+    assert all(w is None or w.shape == (D_MODEL, D_MODEL) for w in ws) and (ws[1] is None) == (ws[2] is None)
+    lib = _lib.load()
+    dev = next(w for w in ws if w is not None).device
+    out = torch.empty(lib.scream_proj_image_bytes(int(ws[0] is not None), int(ws[1] is not None)), device=dev, dtype=torch.uint8)
+    check(lib.scream_pack_proj_x3(*(None if w is None else _p(w) for w in ws), _p(out, torch.uint8), _stream()), "scream_pack_proj_x3")
+    return out
+
+
+def proj_x3(x: torch.Tensor, image: torch.Tensor, has_q: bool, has_kv: bool, tile_cloud=None, cloud_row0=None, cloud_len=None,
+            row_base: int = 0):
+    """q / k / v projections + fused K^T V on the ring-design kernel (scream_proj_x3_f32).  x and the returned Q' are
+    FRAGMENT-major [M,256]; image = pack_proj(...) (for has_kv only, of a full image: image[proj_image_bytes(1, 0):]).
+    Returns (Q' or None, kv_partial [M/128,8,1056] or None)."""
+    M = x.shape[0]
+    assert x.shape[1] == D_MODEL
+    Q = torch.empty(M, D_MODEL, device=x.device, dtype=torch.float32) if has_q else None
+    part = torch.empty(M // ROW_TILE, 8, KV_ELEMS, device=x.device, dtype=torch.float32) if has_kv else None
+    i32 = lambda t: None if t is None else _p(t, torch.int32)
+    check(_lib.load().scream_proj_x3_f32(_p(x), _p(image, torch.uint8), int(has_q), int(has_kv), None if Q is None else _p(Q),
+                                         None if part is None else _p(part), i32(tile_cloud), i32(cloud_row0), i32(cloud_len),
+                                         row_base, M, _stream()), "scream_proj_x3_f32")
+    return Q, part
+
+
 def gemm_qkv(A: torch.Tensor, W: torch.Tensor, n_q: int, tile_cloud, cloud_row0, cloud_len, row_base: int, layout: int = 0):
     """Fused q/k/v projection (scream_gemm_qkv_f32).  Returns (Q' [M,256] or None, kv_partial [M/128,8,1056]).
     layout (split kernel only): LAYOUT_A_FRAG | LAYOUT_C_FRAG."""

@@ -229,6 +229,88 @@ def test_fused_qkv_projection_and_kv_reduce_vs_oracle(kind):
     torch.testing.assert_close(kv2[1], kv[1], rtol=0, atol=0)
 
 
+def test_ring_projection_kernel_vs_oracle_all_three_modes():
+    """scream_proj_x3_f32 (csrc/proj_x3.hip; fragment-major x in, fragment-major Q' out, K^T V partials) against the
+    oracle's intermediates in its three modes -- q|k|v (self layers), q only and k|v only with a row offset (cross layers)
+    -- on two ragged clouds with garbage in the padding rows; and against the 8-wave split GEMM it replaces."""
+    sd = make_state_dict(9, 256, 1, 1)
+    rng = np.random.default_rng(2)
+    lens, row0, rows = [300, 129], [0, 384], 640
+    x = torch.zeros(rows, 256)
+    xs = [torch.from_numpy(rng.normal(size=(n, 256)).astype(np.float32)) for n in lens]
+    for r0, xc in zip(row0, xs):
+        x[r0:r0 + xc.shape[0]] = xc
+    x[300:384] = 3.0  # garbage in padding rows must not reach the reduction
+    x[384 + 129:] = -7.0
+    q, k, v = (sd["stem.0.%s_proj.weight" % n] for n in "qkv")
+    tile_cloud = dev(torch.tensor([0, 0, 0, 1, 1], dtype=torch.int32))
+    crow0, clen = dev(torch.tensor(row0, dtype=torch.int32)), dev(torch.tensor(lens, dtype=torch.int32))
+    img = ops.pack_proj(dev(q), dev(k), dev(v))
+    from scream_amd import _lib
+    lib = _lib.load()
+    assert img.numel() == lib.scream_proj_image_bytes(1, 1) == 24 * 48 * 1024
+    xf = ops.act_layout(dev(x), True)
+    Qf, part = ops.proj_x3(xf, img, True, True, tile_cloud, crow0, clen, 0)
+    Q = ops.act_layout(Qf, False)
+    kv = ops.kv_finalize(part, crow0, clen, 0, 0, 2, 2).cpu()
+    for ci, (r0, xc) in enumerate(zip(row0, xs)):
+        want = {}
+        O.mh_attention(xc[None], xc[None], xc[None], sd, "stem.0.", want)
+        n = xc.shape[0]
+        torch.testing.assert_close(Q[r0:r0 + n].cpu().reshape(n, 8, 32), want["Q"][0], rtol=1e-5, atol=1e-5)
+        kvt = kv[ci, :, :1024].reshape(8, 32, 32)  # [h][v][d]
+        torch.testing.assert_close(kvt.permute(0, 2, 1), want["KV"][0], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(kv[ci, :, 1024:], want["Ksum"][0], rtol=1e-5, atol=1e-4)
+    # the kernel it replaces: same numbers to fp32 rounding (other summation order inside K^T V)
+    W = torch.cat([q, k[:128], v[:128], k[128:], v[128:]], dim=0)
+    Qg, partg = ops.gemm_qkv(xf, ops.split_planes(dev(W)), 256, tile_cloud, crow0, clen, 0, ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG)
+    real = torch.zeros(rows, dtype=torch.bool)
+    for r0, n in zip(row0, lens):
+        real[r0:r0 + n] = True
+    torch.testing.assert_close(Q[real.to(DEV)], ops.act_layout(Qg, False)[real.to(DEV)], rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(part, partg, rtol=1e-5, atol=2e-4)
+    # q only: the first 8 stages of the same image, and an image packed from Wq alone
+    Q1, none = ops.proj_x3(xf, img, True, False)
+    assert none is None and torch.equal(Q1, Qf)
+    Q2, _ = ops.proj_x3(xf, ops.pack_proj(dev(q), None, None), True, False)
+    assert torch.equal(Q2, Qf)
+    # k|v only, rows offset by row_base (the cross layers' target side): bitwise the same partials as the full kernel's
+    off = lib.scream_proj_image_bytes(1, 0)
+    _, part2 = ops.proj_x3(xf[384:], img[off:], False, True, tile_cloud, crow0, clen, 384)
+    assert torch.equal(part2, part[3:])
+    _, part3 = ops.proj_x3(xf[384:], ops.pack_proj(None, dev(k), dev(v)), False, True, tile_cloud, crow0, clen, 384)
+    assert torch.equal(part3, part[3:])
+
+
+def test_ring_projection_kernel_many_tiles_per_block_bitwise_repeatable():
+    """More tiles than the 256 persistent blocks (tile loop, next-tile x requests, the exchange buffer's reuse across tiles):
+    333 312 rows in 65 clouds of odd lengths vs the split GEMM; the launch is bitwise repeatable and does not depend on the
+    number of tiles a block walks (the first rows of a longer launch equal a shorter launch of those rows)."""
+    g = torch.Generator(device=DEV).manual_seed(4)
+    M = 333312
+    n_tiles = M // 128
+    per = 40
+    n_clouds = (n_tiles + per - 1) // per
+    tile_cloud = (torch.arange(n_tiles, device=DEV) // per).int()
+    crow0 = (torch.arange(n_clouds, device=DEV) * per * 128).int()
+    clen = torch.full((n_clouds,), per * 128 - 77, device=DEV, dtype=torch.int32)
+    clen[-1] = M - int(crow0[-1]) - 5
+    x = torch.randn(M, 256, device=DEV, generator=g)
+    Wq, Wk, Wv = (torch.randn(256, 256, device=DEV, generator=g) / 16 for _ in range(3))
+    img = ops.pack_proj(Wq, Wk, Wv)
+    xf = ops.act_layout(x, True)
+    Qf, part = ops.proj_x3(xf, img, True, True, tile_cloud, crow0, clen, 0)
+    Qf2, part2 = ops.proj_x3(xf, img, True, True, tile_cloud, crow0, clen, 0)
+    assert torch.equal(Qf, Qf2) and torch.equal(part, part2)
+    W = torch.cat([Wq, Wk[:128], Wv[:128], Wk[128:], Wv[128:]], dim=0)
+    Qg, partg = ops.gemm_qkv(xf, ops.split_planes(W), 256, tile_cloud, crow0, clen, 0, ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG)
+    torch.testing.assert_close(Qf, Qg, rtol=5e-6, atol=5e-6)
+    torch.testing.assert_close(part, partg, rtol=1e-5, atol=1e-3)
+    rows = 40 * 128 * 3  # three whole clouds
+    Qs, ps = ops.proj_x3(xf[:rows], img, True, True, tile_cloud, crow0, clen, 0)
+    assert torch.equal(Qs, Qf[:rows]) and torch.equal(ps, part[:rows // 128])
+
+
 # ----------------------------------------------------------------- A1-A6 whole forward pass
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_forward_vs_reference_golden(golden, backend):

@@ -6,23 +6,26 @@ compiler does not know those registers are pending until a hand-placed `s_waitcn
 spill or reuse such a register before the wait -- silently reading stale bytes.  This walks every kernel of the file in
 program order with the in-order model of the vector-memory queue (loads, LDS-DMA and stores retire oldest first;
 `vmcnt(N)` leaves the N youngest outstanding) and reports every instruction that touches a VGPR whose load is still
-outstanding.
+outstanding.  Second check (check_scalar_base_hazard): the wait states hipcc does not insert in front of an asm memory
+instruction whose scalar base was just written by a VALU instruction.
 
     python tools/asm_inflight_check.py file.s [kernel-name-substring]
 """
 import re
 import sys
 
-REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
+ACC = 1000  # accumulation registers a0 .. a255 are tracked as 1000 .. 1255 (loads may target them on gfx90a and later)
 
 
 def regs_of(text):
     out = set()
     for m in REG.finditer(text):
         if m.group(1) is not None:
-            out.add(int(m.group(1)))
+            out.add(int(m.group(2)) + (ACC if m.group(1) == "a" else 0))
         else:
-            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+            base = ACC if m.group(3) == "a" else 0
+            out.update(range(base + int(m.group(4)), base + int(m.group(5)) + 1))
     return out
 
 
@@ -104,6 +107,78 @@ def check_kernel(name, body, max_states_per_block=6):
     return [bad[k] for k in sorted(bad)]
 
 
+SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]")
+
+
+def sregs_of(text):
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def check_scalar_base_hazard(name, body, need=5):
+    """gfx9 / CDNA hazard: a VALU instruction that writes an SGPR (v_readlane_b32, v_readfirstlane_b32 -- how hipcc restores
+    a spilled scalar -- or a VALU compare into an SGPR pair) must be `need` wait states away from a vector-memory instruction
+    that reads that SGPR as its address.  hipcc pads its own memory instructions but does not look inside asm statements,
+    which is where this project's register loads and stores with a scalar base live.  Straight-line scan backwards from every
+    global_* instruction with an s[..] address (a label in between only shortens the distance seen: conservative)."""
+    ins = []
+    for raw in body:
+        t = raw.split(";")[0].strip()
+        if not t or t.startswith(".") or t.endswith(":"):
+            continue
+        ins.append(t)
+    bad = []
+    for i, t in enumerate(ins):
+        op = t.split()[0]
+        if not op.startswith("global_") or " s[" not in t:
+            continue
+        addr = sregs_of(t.split(",")[-1])
+        ws = 0
+        for j in range(i - 1, -1, -1):
+            tt = ins[j]
+            o = tt.split()[0]
+            if o.startswith("v_") and not o.startswith("v_mfma") and sregs_of(tt[len(o):].split(",")[0]) & addr:
+                bad.append((i, t, tt, ws))
+                break
+            ws += int(tt.split()[1]) + 1 if o == "s_nop" else 1
+            if ws >= need:
+                break
+    return bad
+
+
+def check_store_data_hazard(name, body, need=2):
+    """gfx9 / CDNA hazard: a vector-memory store of more than 64 bits reads its data VGPRs for a few cycles after issue; a
+    VALU instruction that overwrites one of them within `need` wait states corrupts the stored value.  hipcc pads its own
+    stores; an asm store is opaque to it."""
+    ins = []
+    for raw in body:
+        t = raw.split(";")[0].strip()
+        if not t or t.startswith(".") or t.endswith(":"):
+            continue
+        ins.append(t)
+    bad = []
+    for i, t in enumerate(ins):
+        if not re.match(r"global_store_dwordx[34]\b", t):
+            continue
+        data = regs_of(t.split(",")[1])
+        ws = 0
+        for j in range(i + 1, len(ins)):
+            tt = ins[j]
+            o = tt.split()[0]
+            if o.startswith("v_") and regs_of(tt[len(o):].split(",")[0]) & data:
+                bad.append((i, t, tt, ws))
+                break
+            ws += int(tt.split()[1]) + 1 if o == "s_nop" else 1
+            if ws >= need:
+                break
+    return bad
+
+
 def kernels(path):
     lines = open(path).read().splitlines()
     starts = [(i, l.split(":")[0]) for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
@@ -120,11 +195,23 @@ def main():
         if want not in nm:
             continue
         bad = check_kernel(nm, body)
-        n_asm = sum(1 for l in body if re.match(r"\s*global_load_dwordx4 v", l))
+        n_asm = sum(1 for l in body if re.match(r"\s*global_load_dwordx4 [va]", l))
         print("%s: %d register loads, %d violations" % (nm[:70], n_asm, len(bad)))
         for n, line, regs in bad[:12]:
             print("   +%d  %s   <- pending v%s" % (n, line, regs))
         total += len(bad)
+        hz = check_scalar_base_hazard(nm, body)
+        if hz:
+            print("   %d scalar-base hazards (VALU writes an SGPR < 5 wait states before a memory instruction uses it):" % len(hz))
+            for i, t, tt, ws in hz[:6]:
+                print("      %s  ->  %s   (%d wait states)" % (tt, t, ws))
+        total += len(hz)
+        sd = check_store_data_hazard(nm, body)
+        if sd:
+            print("   %d store-data hazards (VALU overwrites a wide store's data register < 2 wait states behind it):" % len(sd))
+            for i, t, tt, ws in sd[:6]:
+                print("      %s  ;  %s   (%d wait states)" % (t, tt, ws))
+        total += len(sd)
     return 1 if total else 0
 
 
