@@ -380,6 +380,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
     auto seg_base = [&](const float* base, int64_t grp, int seg) { return base + grp + seg * 1024; };
     auto req_q = [&](f32x4 (&qb)[4], int64_t grp, int h) {  // Q' of head h: the one operand that comes from HBM
         if (T_ABLATE & (16 | 32)) return;
+        if (T_ABLATE & 2048) grp = (int64_t)wave * 32 * SCREAM_D_MODEL;  // tuning aid: always the first tile's rows (cache hits)
         ld_asm4<1024>(qb, seg_base(Q, grp, h), v_lane16);
     };
     auto req_head = [&](HeadOps& o, const char* kvc, int h) {  // KV^T fragments and Ksum of head h: L2-hot per-cloud data
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
     };
     auto req_x = [&](f32x4 (&xs)[4], int64_t grp, int blk) {
         if (T_ABLATE & (16 | 64)) return;
+        if (T_ABLATE & 2048) grp = (int64_t)wave * 32 * SCREAM_D_MODEL;
         ld_asm4<1024>(xs, seg_base(xres, grp, blk), v_lane16);
     };
     auto pin_head = [&](HeadOps& o) {
