@@ -46,6 +46,9 @@ sys.path.insert(0, REPO)
 PAIRS_PER_GPU = 32
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_BF16_DENSE_TFLOPS = 2500.0  # same table; the split GEMM spends six bf16 MFMAs per fp32 product
+# context only, never `peak`: what a pure stream of v_mfma_f32_32x32x16_bf16 on random register operands sustains at the
+# 1400 W socket cap (tools/ubench/mfma_energy.py, profiles/r02_ubench_mfma_energy.txt: 1.84 PFLOP/s at 1.80 GHz)
+MEASURED_BF16_MFMA_AT_POWER_CAP_TFLOPS = 1840.0
 GEMM_NAMES = {0: "gemm<EPI_NONE>", 1: "gemm<EPI_ELU1> (cross-layer q projection)",
               5: "gemm<EPI_QKV> (q/k/v projection + fused K^T V reduce)",
               6: "ffn_x3_kernel (FFN 256->1024, relu, 1024->256 + residual + LayerNorm in one launch)",
@@ -495,6 +498,7 @@ def main():
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "mfma_tflops_issued": round(achieved * (6 if x3 else 1), 1),
                          "frac_of_fp32_matrix_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
+                         **({"frac_of_measured_mfma_rate_at_power_cap": round(achieved * 6 / MEASURED_BF16_MFMA_AT_POWER_CAP_TFLOPS, 4)} if x3 else {}),
                          "launches": gemm_launches, "avg_ms": round(gemm_ms / gemm_launches, 4),
                          "busy_ms_per_step": round(gemm_busy_ms / args.steps, 3),
                          "summed_launch_ms_per_step": round(gemm_ms / args.steps, 3),
