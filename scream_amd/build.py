@@ -26,6 +26,7 @@ SOURCES = {
     "forward.hip": [],
     "nn_search.hip": ["-ffp-contract=off"],
     "kabsch.hip": ["-ffp-contract=off"],
+    "icp_grid.hip": ["-ffp-contract=off"],
 }
 ASM_LOADS = ("gemm_x3.hip", "tail_x3.hip", "proj_x3.hip")  # verified after code generation, see verify_one
 

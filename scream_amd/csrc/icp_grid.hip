@@ -1,0 +1,238 @@
+// Radius-limited nearest neighbour for the ICP loop (scream_icp_p2p, kabsch.hip) on a uniform grid over the TARGET cloud.
+//
+// open3d's registration_icp, which the reference calls after every prediction (evaluate_3d_match.py:106-119,
+// evaluate_kitti.py:63-76), only ever uses correspondences closer than max_correspondence_distance, and the target cloud does
+// not move during the loop.  The brute-force search of nn_search.hip evaluates every source x target distance in every
+// iteration (25 M per 5 k-point pair, 250 M at KITTI size, times 30 .. 1000 iterations); here the targets are binned once per
+// call into cells of edge h >= 1.01 x the radius, and a query looks at the 27 cells around its own.
+//
+// Same results, bit for bit, wherever the brute-force search reports a valid correspondence: a candidate's distance is
+// computed by the same explicitly rounded sequence (|a|^2 - 2 a.b + |b|^2 in nn_search_kernel's order, on the same
+// pre-divided target records), ties go to the lowest ORIGINAL target index, and every target whose computed distance is
+// below the threshold lies in the 27 cells (the 1 % margin on h is four orders of magnitude above the rounding of the
+// cell arithmetic and of the distance).  Where no target is inside the radius the brute-force search still returns the
+// global nearest neighbour with valid = 0; this one returns idx = -1, dmin = inf, valid = 0 -- the ICP update reads
+// neither for such a point (icp_update_kernel, kabsch_block: valid only).
+//
+// Build, once per scream_icp_p2p call: bounding box per pair -> grid parameters (the cell edge grows by 2^(1/3) until the
+// grid fits ICP_GRID_CELLS cells: correct for any h >= the radius, only more candidates) -> count -> exclusive scan ->
+// scatter of the prepared records {b, |b|^2} and their original indices in cell order.  Cell index = (z ny + y) nx + x, so
+// the three x-neighbours of a cell are one contiguous run and a query scans nine runs.
+#include "common.h"
+#include "icp_grid.h"
+
+namespace {
+
+struct GridParam {  // per pair
+    float ox, oy, oz, inv_h;
+    int32_t nx, ny, nz, ncell;
+};
+
+__device__ __forceinline__ int cell_coord(float x, float o, float inv_h, int n) {
+    const int c = (int)floorf((x - o) * inv_h);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+// grid n_pairs, block 256: bounding box of the pair's targets (metric coordinates) and the grid over it
+__global__ __launch_bounds__(256) void grid_params_kernel(const float* __restrict__ ref, const int32_t* __restrict__ r_row0,
+                                                         const int32_t* __restrict__ r_len, float h0,
+                                                         GridParam* __restrict__ gp) {
+    __shared__ float red[6][256];
+    const int p = blockIdx.x, n = r_len[p];
+    const int64_t r0 = r_row0[p];
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = threadIdx.x; i < n; i += 256)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = ref[(r0 + i) * 3 + k];
+            lo[k] = fminf(lo[k], v);
+            hi[k] = fmaxf(hi[k], v);
+        }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        red[k][threadIdx.x] = lo[k];
+        red[3 + k][threadIdx.x] = hi[k];
+    }
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                red[k][threadIdx.x] = fminf(red[k][threadIdx.x], red[k][threadIdx.x + s]);
+                red[3 + k][threadIdx.x] = fmaxf(red[3 + k][threadIdx.x], red[3 + k][threadIdx.x + s]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        GridParam g;
+        if (n <= 0) {
+            g = GridParam{0.f, 0.f, 0.f, 1.f, 1, 1, 1, 1};
+        } else {
+            float h = h0;
+            int nx, ny, nz;
+            for (;;) {  // one spare cell on either side: a query within the radius of the box still maps next to its targets
+                nx = (int)floorf((red[3][0] - red[0][0]) / h) + 3;
+                ny = (int)floorf((red[4][0] - red[1][0]) / h) + 3;
+                nz = (int)floorf((red[5][0] - red[2][0]) / h) + 3;
+                if ((int64_t)nx * ny * nz <= ICP_GRID_CELLS) break;
+                h *= 1.26f;
+            }
+            g = GridParam{red[0][0] - h, red[1][0] - h, red[2][0] - h, 1.0f / h, nx, ny, nz, nx * ny * nz};
+        }
+        gp[p] = g;
+    }
+}
+
+// grid (ceil(max_r_len / 256), n_pairs)
+__global__ __launch_bounds__(256) void grid_count_kernel(const float* __restrict__ ref, const int32_t* __restrict__ r_row0,
+                                                        const int32_t* __restrict__ r_len, const GridParam* __restrict__ gp,
+                                                        int32_t* __restrict__ count, int32_t* __restrict__ cell_of) {
+    const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= r_len[p]) return;
+    const GridParam g = gp[p];
+    const int64_t row = (int64_t)r_row0[p] + i;
+    const int cx = cell_coord(ref[row * 3 + 0], g.ox, g.inv_h, g.nx), cy = cell_coord(ref[row * 3 + 1], g.oy, g.inv_h, g.ny),
+              cz = cell_coord(ref[row * 3 + 2], g.oz, g.inv_h, g.nz);
+    const int c = (cz * g.ny + cy) * g.nx + cx;
+    cell_of[row] = c;
+    atomicAdd(count + (int64_t)p * (ICP_GRID_CELLS + 1) + c, 1);
+}
+
+// grid n_pairs, block 1024: in-place exclusive scan of count[p][0 .. ncell] (entry ncell = total), and a copy as the
+// scatter cursors
+__global__ __launch_bounds__(1024) void grid_scan_kernel(const GridParam* __restrict__ gp, int32_t* __restrict__ count,
+                                                        int32_t* __restrict__ cursor) {
+    __shared__ int32_t part[1024];
+    const int p = blockIdx.x, t = threadIdx.x;
+    const int ncell = gp[p].ncell;
+    int32_t* c = count + (int64_t)p * (ICP_GRID_CELLS + 1);
+    int32_t* cur = cursor + (int64_t)p * ICP_GRID_CELLS;
+    const int chunk = (ncell + 1023) / 1024;
+    const int b = t * chunk, e = min(ncell, b + chunk);
+    int32_t s = 0;
+    for (int i = b; i < e; ++i) s += c[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // inclusive scan of the per-thread sums
+        const int32_t v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int32_t run = part[t] - s;
+    for (int i = b; i < e; ++i) {
+        const int32_t v = c[i];
+        c[i] = run;
+        cur[i] = run;
+        run += v;
+    }
+    if (t == 1023) c[ncell] = part[1023];
+}
+
+// grid (ceil(max_r_len / 256), n_pairs): the prepared records and original indices in cell order
+__global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restrict__ ref_prep, const int32_t* __restrict__ r_row0,
+                                                          const int32_t* __restrict__ r_len, const int32_t* __restrict__ cell_of,
+                                                          int32_t* __restrict__ cursor, float* __restrict__ sorted_prep,
+                                                          int32_t* __restrict__ sorted_idx) {
+    const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= r_len[p]) return;
+    const int64_t r0 = r_row0[p], row = r0 + i;
+    const int pos = atomicAdd(cursor + (int64_t)p * ICP_GRID_CELLS + cell_of[row], 1);
+    *reinterpret_cast<f32x4*>(sorted_prep + (r0 + pos) * 4) = *reinterpret_cast<const f32x4*>(ref_prep + row * 4);
+    sorted_idx[r0 + pos] = i;
+}
+
+// grid (ceil(max_q_len / 256), n_pairs): one query per thread; same rounding sequence as nn_search_kernel with s = 1
+__global__ __launch_bounds__(256) void grid_search_kernel(const float* __restrict__ query, const int32_t* __restrict__ q_row0,
+                                                         const int32_t* __restrict__ q_len, const int32_t* __restrict__ r_row0,
+                                                         const GridParam* __restrict__ gp, const int32_t* __restrict__ start,
+                                                         const float* __restrict__ sorted_prep,
+                                                         const int32_t* __restrict__ sorted_idx, float thresh,
+                                                         int32_t* __restrict__ idx, float* __restrict__ dmin,
+                                                         uint8_t* __restrict__ valid) {
+    const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= q_len[p]) return;
+    const GridParam g = gp[p];
+    const int64_t row = (int64_t)q_row0[p] + i;
+    const float ax = query[row * 3 + 0], ay = query[row * 3 + 1], az = query[row * 3 + 2];
+    const float sa = __fadd_rn(__fadd_rn(__fmul_rn(ax, ax), __fmul_rn(ay, ay)), __fmul_rn(az, az));
+    const int cx = cell_coord(ax, g.ox, g.inv_h, g.nx), cy = cell_coord(ay, g.oy, g.inv_h, g.ny), cz = cell_coord(az, g.oz, g.inv_h, g.nz);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+    const int32_t* st = start + (int64_t)p * (ICP_GRID_CELLS + 1);
+    const float* sp = sorted_prep + (int64_t)r_row0[p] * 4;
+    const int32_t* si = sorted_idx + r_row0[p];
+    float best = __builtin_inff();
+    int bi = 0x7fffffff;
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.nz - 1); ++z)
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.ny - 1); ++y) {
+            const int c0 = (z * g.ny + y) * g.nx;
+            const int jb = st[c0 + x0], je = st[c0 + x1 + 1];
+            for (int j = jb; j < je; ++j) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(sp + (int64_t)j * 4);
+                float dot = __fmul_rn(ax, b[0]);
+                dot = __fmaf_rn(ay, b[1], dot);
+                dot = __fmaf_rn(az, b[2], dot);
+                const float d = __fadd_rn(__fmaf_rn(-2.0f, dot, sa), b[3]);
+                const int o = si[j];
+                if (d < best || (d == best && o < bi)) {
+                    best = d;
+                    bi = o;
+                }
+            }
+        }
+    const bool ok = best < thresh;
+    idx[row] = ok ? bi : -1;
+    dmin[row] = ok ? best : __builtin_inff();
+    valid[row] = ok ? 1 : 0;
+}
+
+}  // namespace
+
+namespace scream_internal {
+
+int64_t icp_grid_workspace_floats(int64_t ref_rows_total, int32_t n_pairs) {
+    // params (8) + count/start (CELLS + 1) + cursor (CELLS) per pair; cell_of (1) + sorted record (4) + sorted index (1) per target
+    return (int64_t)n_pairs * (8 + 2 * (int64_t)ICP_GRID_CELLS + 1) + ref_rows_total * 6 + 5 * 64;
+}
+
+int icp_grid_build(const float* ref_m, const float* ref_prep, const int32_t* r_row0, const int32_t* r_len, int32_t n_pairs,
+                   int32_t max_r_len, int64_t ref_rows_total, float radius, float* work, IcpGrid* out, hipStream_t st) {
+    float* w = work;
+    auto take = [&](int64_t n) { float* r = w; w += (n + 63) / 64 * 64; return r; };
+    GridParam* gp = reinterpret_cast<GridParam*>(take((int64_t)n_pairs * 8));
+    int32_t* count = reinterpret_cast<int32_t*>(take((int64_t)n_pairs * (ICP_GRID_CELLS + 1)));
+    int32_t* cursor = reinterpret_cast<int32_t*>(take((int64_t)n_pairs * ICP_GRID_CELLS));
+    int32_t* cell_of = reinterpret_cast<int32_t*>(take(ref_rows_total));
+    float* sorted_prep = take(ref_rows_total * 4);
+    int32_t* sorted_idx = reinterpret_cast<int32_t*>(take(ref_rows_total));
+    out->params = gp;
+    out->start = count;
+    out->sorted_prep = sorted_prep;
+    out->sorted_idx = sorted_idx;
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t) * (size_t)n_pairs * (ICP_GRID_CELLS + 1), st);
+    if (e != hipSuccess) return (int)e;
+    grid_params_kernel<<<dim3(n_pairs), dim3(256), 0, st>>>(ref_m, r_row0, r_len, radius * 1.01f, gp);
+    SCREAM_LAUNCH_CHECK();
+    if (max_r_len > 0) {
+        const dim3 grid((max_r_len + 255) / 256, n_pairs);
+        grid_count_kernel<<<grid, dim3(256), 0, st>>>(ref_m, r_row0, r_len, gp, count, cell_of);
+        SCREAM_LAUNCH_CHECK();
+        grid_scan_kernel<<<dim3(n_pairs), dim3(1024), 0, st>>>(gp, count, cursor);
+        SCREAM_LAUNCH_CHECK();
+        grid_scatter_kernel<<<grid, dim3(256), 0, st>>>(ref_prep, r_row0, r_len, cell_of, cursor, sorted_prep, sorted_idx);
+        SCREAM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int icp_grid_search(const IcpGrid& g, const float* query, const int32_t* q_row0, const int32_t* q_len, const int32_t* r_row0,
+                    int32_t n_pairs, int32_t max_q_len, float thresh, int32_t* idx, float* dmin, uint8_t* valid, hipStream_t st) {
+    if (max_q_len <= 0 || n_pairs <= 0) return 0;
+    grid_search_kernel<<<dim3((max_q_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(
+        query, q_row0, q_len, r_row0, reinterpret_cast<const GridParam*>(g.params), g.start, g.sorted_prep, g.sorted_idx, thresh, idx,
+        dmin, valid);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace scream_internal

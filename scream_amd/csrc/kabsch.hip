@@ -12,7 +12,10 @@
 // reference's individually rounded operations.
 #include <vector>
 
+#include <stdlib.h>
+
 #include "common.h"
+#include "icp_grid.h"
 
 namespace {
 
@@ -456,7 +459,9 @@ extern "C" int scream_transformation_error(const float* T_pred, const float* T_g
 extern "C" int64_t scream_icp_workspace_bytes(int64_t src_rows_total, int64_t ref_rows_total, int32_t n_pairs) {
     if (src_rows_total < 0 || ref_rows_total < 0 || n_pairs < 0) return SCREAM_EINVAL;
     // src metric + transformed src (3 floats each), ref metric (3) + nn ref_prep (4), keys (2), idx, dmin, valid, ones, state
-    return (src_rows_total * (3 + 3 + 2 + 1 + 1 + 1) + ref_rows_total * (3 + 4) + (int64_t)n_pairs * 16) * 4 + 8192;
+    // + the target grid of icp_grid.hip
+    return (src_rows_total * (3 + 3 + 2 + 1 + 1 + 1) + ref_rows_total * (3 + 4) + (int64_t)n_pairs * 16 +
+            scream_internal::icp_grid_workspace_floats(ref_rows_total, n_pairs)) * 4 + 8192;
 }
 
 extern "C" int scream_icp_p2p(const float* src, const float* ref, const int32_t* src_row0, const int32_t* src_len,
@@ -483,7 +488,11 @@ extern "C" int scream_icp_p2p(const float* src, const float* ref, const int32_t*
     float* ones = take(n_pairs);
     IcpState* state = reinterpret_cast<IcpState*>(take((int64_t)n_pairs * 4));
     int32_t* act_len = reinterpret_cast<int32_t*>(take(n_pairs));
+    float* grid_work = take(scream_internal::icp_grid_workspace_floats(ref_rows_total, n_pairs));
     SCREAM_REQUIRE(reinterpret_cast<char*>(w) <= reinterpret_cast<char*>(workspace) + workspace_bytes, SCREAM_EINVAL);
+    // SCREAM_ICP_BRUTE=1 (tests): every iteration on the brute-force search of nn_search.hip instead of the target grid
+    const char* brute_env = getenv("SCREAM_ICP_BRUTE");
+    const bool brute = brute_env && brute_env[0] == '1';
 
     hipError_t e = hipMemsetAsync(state, 0, sizeof(IcpState) * n_pairs, st);
     if (e != hipSuccess) return (int)e;
@@ -496,14 +505,26 @@ extern "C" int scream_icp_p2p(const float* src, const float* ref, const int32_t*
     if (max_ref_len > 0)
         icp_to_metric_kernel<<<dim3((max_ref_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(ref, ref_row0, ref_len, s, c, ref_m);
     SCREAM_LAUNCH_CHECK();
+    scream_internal::IcpGrid grid{};
+    if (!brute) {  // the targets do not move: prepare and bin them once (icp_grid.hip)
+        int rc = scream_internal::nn_prepare_targets(ref_m, ref_row0, ref_len, ones, n_pairs, max_ref_len, ref_prep, st);
+        if (rc != 0) return rc;
+        rc = scream_internal::icp_grid_build(ref_m, ref_prep, ref_row0, ref_len, n_pairs, max_ref_len, ref_rows_total, max_corr_dist,
+                                             grid_work, &grid, st);
+        if (rc != 0) return rc;
+        rc = scream_internal::nn_fill_padding(idx, dmin, valid, src_rows_total, st);
+        if (rc != 0) return rc;
+    }
     std::vector<IcpState> host_state;
     for (int it = 0; it <= max_iter; ++it) {
         if (max_src_len > 0)
             icp_transform_kernel<<<dim3((max_src_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(src_m, src_row0, act_len, T, q);
         SCREAM_LAUNCH_CHECK();
-        int rc = scream_nn_search(q, ref_m, src_row0, act_len, ref_row0, ref_len, ones, n_pairs, max_src_len, max_ref_len,
-                                  src_rows_total, ref_rows_total, max_corr_dist * max_corr_dist, ref_prep, keys, idx, dmin,
-                                  valid, stream);
+        int rc = brute ? scream_nn_search(q, ref_m, src_row0, act_len, ref_row0, ref_len, ones, n_pairs, max_src_len, max_ref_len,
+                                          src_rows_total, ref_rows_total, max_corr_dist * max_corr_dist, ref_prep, keys, idx, dmin,
+                                          valid, stream)
+                       : scream_internal::icp_grid_search(grid, q, src_row0, act_len, ref_row0, n_pairs, max_src_len,
+                                                          max_corr_dist * max_corr_dist, idx, dmin, valid, st);
         if (rc != 0) return rc;
         icp_update_kernel<<<dim3(n_pairs), dim3(256), 0, st>>>(q, ref_m, src_row0, src_len, ref_row0, idx, valid, dmin, it,
                                                                max_iter, rel_fitness, rel_rmse, T, state, act_len,

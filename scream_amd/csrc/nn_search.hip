@@ -12,6 +12,7 @@
 // (broadcast) ds_read_b128; each thread carries QPT query points, so one LDS read feeds QPT x 8 VALU
 // ops.  The kernel is VALU-bound (8 flop per pair over 12 bytes per POINT), not HBM-bound.
 #include "common.h"
+#include "icp_grid.h"
 
 namespace {
 
@@ -173,6 +174,25 @@ __global__ __launch_bounds__(256) void square_distance_kernel(const float* __res
 }
 
 }  // namespace
+
+namespace scream_internal {  // icp_grid.h: shared with the ICP loop
+
+int nn_prepare_targets(const float* ref, const int32_t* r_row0, const int32_t* r_len, const float* s, int32_t n_pairs,
+                       int32_t max_r_len, float* ref_prep, hipStream_t st) {
+    if (max_r_len <= 0 || n_pairs <= 0) return 0;
+    nn_prep_kernel<<<dim3((max_r_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(ref, r_row0, r_len, s, ref_prep);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nn_fill_padding(int32_t* idx, float* dmin, uint8_t* valid, int64_t n, hipStream_t st) {
+    if (n <= 0) return 0;
+    nn_fill_padding_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(idx, dmin, valid, n);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace scream_internal
 
 extern "C" int scream_square_distance(const float* src, const float* dst, float* out, int32_t B, int32_t N, int32_t M,
                                       void* stream) {

@@ -126,6 +126,60 @@ def test_gpu_icp_vs_oracle_loop():
         assert 1 <= iters[i] <= 30 and abs(int(iters[i]) - n_it) <= 3
 
 
+@pytest.mark.parametrize("kind", ["3dmatch", "kitti"])
+def test_gpu_icp_grid_search_equals_brute_force_bitwise(kind, monkeypatch):
+    """The ICP loop looks for correspondences on a uniform grid over the (fixed) target cloud (csrc/icp_grid.hip).  Wherever
+    the brute-force search of nn_search.hip reports a valid correspondence the grid reports the same index and the same
+    distance bit for bit, so whole ICP runs -- poses, fitness, RMSE, iteration counts -- are IDENTICAL to runs with
+    SCREAM_ICP_BRUTE=1, on 3DMatch-size pairs (radius 0.1 m, 30 iterations, incl. a one-point target and a source far from
+    its target) and on KITTI-size pairs (13-16 k points, whose extent makes the grid coarsen its cells)."""
+    from scream_amd import ops
+    from scream_amd.packing import PackedBatch
+    from scream_amd.synthetic import make_kitti_pair
+    from scream_amd.data import normalize_pair
+    rng = np.random.default_rng(3)
+    if kind == "3dmatch":
+        items = [SyntheticPairs("3dmatch", 3, seed0=80)[i] for i in range(3)]
+        radius, iters = 0.1, 30
+    else:
+        items = []
+        for j in range(2):
+            src, tgt, rot, trans, s_, c_ = normalize_pair(*make_kitti_pair(20 + j), "bbox")
+            items.append((src, tgt, rot, trans, s_, None, None, c_))
+        radius, iters = 0.6, 40
+    srcs, tgts = [it[0].to(DEV) for it in items], [it[1].to(DEV) for it in items]
+    if kind == "3dmatch":
+        tgts[2] = tgts[2][:1].contiguous()            # a one-point target cloud
+        srcs.append(srcs[0] + 50.0); tgts.append(tgts[0])  # a source nowhere near its target: no correspondence at all
+        items.append(items[0])
+    batch = PackedBatch.from_pairs(srcs, tgts, None)
+    s = torch.tensor([it[4] for it in items], dtype=torch.float32, device=DEV)
+    c = torch.stack([it[7] for it in items]).to(DEV)
+    T0 = []
+    for it in items:
+        Tgt = O.gt_pose_metric(it[2], it[3], it[4], it[7]).double().numpy()
+        ang = np.radians(1.0)
+        P = np.eye(4)
+        P[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+        P[:3, 3] = rng.normal(scale=0.02, size=3)
+        T0.append(P @ Tgt)
+    T0 = torch.from_numpy(np.stack(T0)).float().to(DEV)
+    tgt_row0 = (batch.tgt_row0 - batch.rows_src).contiguous()
+    args = (batch.xyz[: batch.rows_src], batch.xyz[batch.rows_src:], batch.src_row0, batch.src_len_dev, tgt_row0,
+            batch.tgt_len_dev, s, c, T0, max(batch.src_len), max(batch.tgt_len), radius, iters)
+    monkeypatch.delenv("SCREAM_ICP_BRUTE", raising=False)
+    got = ops.icp_p2p(*args)
+    monkeypatch.setenv("SCREAM_ICP_BRUTE", "1")
+    want = ops.icp_p2p(*args)
+    monkeypatch.delenv("SCREAM_ICP_BRUTE", raising=False)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b), (a, b)
+    fit = got[1][:, 0].cpu().numpy()
+    assert fit[0] > 0.3 and fit[1] > 0.3   # real registrations: most points have a partner inside the radius
+    if kind == "3dmatch":
+        assert fit[3] == 0.0                 # the displaced source found nothing, on both paths
+
+
 def test_gpu_icp_matches_oracle_iteration_by_iteration():
     """The same loop, compared where it is well defined: ONE update from the same start uses the same correspondences
     on both sides, so device and oracle must agree to 1e-4 Frobenius.  The starts are the oracle's own iterates
