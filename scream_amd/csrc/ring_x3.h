@@ -121,7 +121,6 @@ __device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&w)[3], const b
 }
 
 
-__device__ __forceinline__ void ld_asm(f32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p)); }
 // Register loads address memory as (wave-uniform base in SGPRs) + (32-bit per-lane offset in ONE VGPR) + immediate: the
 // bases are scalar arithmetic, and no load needs a 64-bit VGPR address of its own (dozens of those, precomputed per tile
 // by hipcc, were what spilled at the tile boundaries).
@@ -186,7 +185,6 @@ __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 
 // s_waitcnt vmcnt(N) alone, as an asm statement: ordered against the other asm statements (slab reads, register loads)
 #define VM_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-#define LGKM_WAIT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // acc += W . act, plain (no scheduling directives): for the short products that ride inside another stage's groups
 __device__ __forceinline__ void mfma6_free(f32x16& acc, const bf16x8 (&w)[3], const bf16x8 (&a)[3], bool zero = false) {
