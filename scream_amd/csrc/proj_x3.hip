@@ -71,21 +71,67 @@ __global__ __launch_bounds__(TT, 1) void proj_x3_kernel(const float* __restrict_
     const int half = lane >> 5, r = lane & 31;
     const unsigned v_lane16 = lane * 16;
     char* xch = smem + T_SLOTS * T_STAGE;
-    auto dma_piece = [&](unsigned q, int u) __attribute__((always_inline)) {
-        const unsigned src = q % (unsigned)NS, slot = q % (unsigned)T_SLOTS;
-        const char* sbase = reinterpret_cast<const char*>(Wimg) + (size_t)src * T_STAGE + (wave * 12 + (u & ~3)) * 1024;
+    // ---- work items -----------------------------------------------------------------------------------------------------
+    // A block walks whole tiles (tile = block + k * grid) for the n_full rounds every block takes part in; the tiles left
+    // over are cut into PARTS items by stage range -- the query chunks and the heads are independent outputs, so the parts of
+    // a tile need no reduction and a row's result does not depend on how its tile was cut -- and dealt out the same way.
+    // With 1300 tiles on 256 CUs the last round then costs a third of a tile instead of a whole one.
+    constexpr int NQ8 = HAS_Q ? 8 : 0;
+    constexpr int PARTS = (HAS_Q && HAS_KV) ? 3 : 2;
+    struct Item {
+        int tile, c0, c1, h0, h1;  // query chunks [c0, c1) (even bounds), heads [h0, h1); tile < 0: none
+    };
+    const int G = (int)gridDim.x;
+    const int n_full = n_tiles >= G && G == T_MAX_GRID ? n_tiles / G : 0;  // (a launch with fewer items than CUs is all parts)
+    const int n_left = n_tiles - n_full * G;
+    auto item_of = [&](int k) __attribute__((always_inline)) {
+        Item it{-1, 0, 0, 0, 0};
+        if (k < n_full) {
+            it = Item{(int)blockIdx.x + k * G, 0, NQ8, 0, HAS_KV ? 8 : 0};
+        } else {
+            const int u = (int)blockIdx.x + (k - n_full) * G;
+            if (u < n_left * PARTS) {
+                const int part = u % PARTS;
+                it.tile = n_full * G + u / PARTS;
+                if (HAS_Q && HAS_KV) {  // 12 + 6 + 6 stages; every part ends with heads (one kind of item end in this kernel)
+                    if (part == 0) { it.c1 = 8; it.h1 = 2; }
+                    else { it.h0 = 3 * part - 1; it.h1 = it.h0 + 3; }
+                } else if (HAS_Q) {
+                    it.c0 = 4 * part; it.c1 = it.c0 + 4;
+                } else {
+                    it.h0 = 4 * part; it.h1 = it.h0 + 4;
+                }
+            }
+        }
+        return it;
+    };
+    auto item_len = [&](const Item& it) __attribute__((always_inline)) { return (it.c1 - it.c0) + 2 * (it.h1 - it.h0); };
+    auto item_img = [&](const Item& it, int pos) __attribute__((always_inline)) {  // image stage of the item's stage number pos
+        const int nq = it.c1 - it.c0;
+        const int k = pos - nq;
+        return pos < nq ? it.c0 + pos : NQ8 + 2 * (it.h0 + (k >> 1)) + (k & 1);
+    };
+    int item_no = 0;
+    Item cur = item_of(0), nxt = item_of(1);
+    int pos = 0;       // stage of `cur` about to be consumed
+    unsigned q = 0;    // stages consumed so far (ring slot = q % 3)
+    auto img_ahead = [&](int d) __attribute__((always_inline)) {  // image stage of the stage d steps ahead in the block's sequence
+        const int p = pos + d, len = item_len(cur);
+        if (p < len) return item_img(cur, p);
+        return nxt.tile >= 0 ? item_img(nxt, p - len) : 0;  // (past the end: any stage, never read)
+    };
+    auto dma_piece = [&](int img, unsigned slot_q, int u) __attribute__((always_inline)) {
+        const unsigned slot = slot_q % (unsigned)T_SLOTS;
+        const char* sbase = reinterpret_cast<const char*>(Wimg) + (size_t)img * T_STAGE + (wave * 12 + (u & ~3)) * 1024;
         dma_1k(sbase + v_lane16, smem + slot * T_STAGE + (wave * 12 + (u & ~3)) * 1024, u & 3);
     };
-    unsigned q = 0;  // next stage to be consumed
+    if (cur.tile < 0) return;
+    {
+        const int i0 = img_ahead(0), i1 = img_ahead(1);
 #pragma unroll
-    for (int u = 0; u < 12; ++u) dma_piece(0, u);
+        for (int u = 0; u < 12; ++u) dma_piece(i0, 0, u);
 #pragma unroll
-    for (int u = 0; u < 12; ++u) dma_piece(1, u);
-
-    int tile = blockIdx.x;
-    if (tile >= n_tiles) {
-        VM_WAIT(0);
-        return;
+        for (int u = 0; u < 12; ++u) dma_piece(i1, 1, u);
     }
     // (every lambda of this kernel is always_inline: one that hipcc leaves out of line takes xp / raw by address and both
     // arrays then live in scratch)
@@ -116,16 +162,16 @@ __global__ __launch_bounds__(TT, 1) void proj_x3_kernel(const float* __restrict_
         const int b = i >> 1, s2 = i & 1;
         split3(raw[b][2 * s2], raw[b][2 * s2 + 1], xp[i][0], xp[i][1], xp[i][2]);
     };
-    request_x(tile);
+    request_x(cur.tile);
     VM_WAIT(0);
     split_x();
 
     while (true) {
-        // (the stage counter is made opaque once per tile: with 8 unrolled stages per tile hipcc otherwise sees that the piece
-        // addresses repeat, hoists two dozen 64-bit per-lane addresses out of the tile loop and spills them)
-        asm volatile("" : "+s"(q));
-        const int tile_next = tile + (int)gridDim.x;
-        const bool has_next = tile_next < n_tiles;
+        asm volatile("" : "+s"(q));  // (opaque once per item: hipcc otherwise hoists per-stage addresses out of the loop and spills them)
+        const int tile = cur.tile;
+        const bool has_next = nxt.tile >= 0;
+        const int tile_next = nxt.tile;
+        const bool has_q = cur.c1 > cur.c0, has_kv = cur.h1 > cur.h0;  // what this item computes
         const int64_t grp = ((int64_t)tile * 128 + wave * 32) * SCREAM_D_MODEL;  // first float of the wave's 32-row group
         int valid_w = 32;  // real tokens among the wave's 32 rows (padding rows do not exist for K^T V)
         if (HAS_KV) {
@@ -151,6 +197,7 @@ __global__ __launch_bounds__(TT, 1) void proj_x3_kernel(const float* __restrict_
             constexpr int XMODE = decltype(xmode)::value;
             ring_barrier<12>();
             __builtin_amdgcn_sched_barrier(0);
+            const int img2 = img_ahead(2);  // the stage whose weights this one requests
             if (XMODE == 1) request_x(has_next ? tile_next : tile);
             if (XMODE == 2) pin_x();
             __builtin_amdgcn_sched_barrier(0);
@@ -168,13 +215,14 @@ __global__ __launch_bounds__(TT, 1) void proj_x3_kernel(const float* __restrict_
                     for (int p = 0; p < 3; ++p)
                         (g + T_PF - 1 == 15 ? wfd[p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag(wb + (p * 16 + g + T_PF - 1) * 1024);
                 }
-                if (g < 12) dma_piece(q + 2, g);
+                if (g < 12) dma_piece(img2, q + 2, g);
                 ride(g);
                 if (XMODE == 2 && g >= 1) split_one(g - 1);
                 if (KIND == 0) mfma6<4>(acc, wf[g % T_PF], xp[g], g == 0);
                 else mfma6<4>(acc, xp[g], wf[g % T_PF], g == 0);
             }
             ++q;
+            ++pos;
         };
         constexpr std::integral_constant<int, 0> kindQ{};
         constexpr std::integral_constant<int, 1> kindKV{};
@@ -284,52 +332,64 @@ __global__ __launch_bounds__(TT, 1) void proj_x3_kernel(const float* __restrict_
             if (g == 12) xch_write();
         };
 
-        // ---- the stages ---------------------------------------------------------------------------------------------------
+        // ---- the stages of this item --------------------------------------------------------------------------------------
+        // Its last two stages request the next item's rows and split them in place (x1 / x2).  Every item of a kernel ends the
+        // same way (query chunks in the q-only kernel, heads in the other two): with request sites on different paths hipcc
+        // assumes a path on which none runs, keeps the 128 row registers of the previous item alive through the whole body
+        // and spills.
 #define LAMBDA(...) [&](__VA_ARGS__) __attribute__((always_inline))
-        if (HAS_Q) {
-            // the last two stages of a query-only tile are chunks 6 and 7
-            constexpr std::integral_constant<int, HAS_KV ? 0 : 1> xq6{};
-            constexpr std::integral_constant<int, HAS_KV ? 0 : 2> xq7{};
-#define QSTAGE(c, xm, cur, prev)                                                     \
-            stage(kindQ, xm, cur, LAMBDA() { if ((c) > 0) flush_q(prev); },            \
-                  LAMBDA(int g) { if ((c) > 0 && g >= 1 && g <= 4) q_epilogue(prev, (c) - 1, g - 1); });
-            QSTAGE(0, x0, tA, tB) QSTAGE(1, x0, tB, tA) QSTAGE(2, x0, tA, tB) QSTAGE(3, x0, tB, tA)
-            QSTAGE(4, x0, tA, tB) QSTAGE(5, x0, tB, tA) QSTAGE(6, xq6, tA, tB) QSTAGE(7, xq7, tB, tA)
-#undef QSTAGE
+#define QPAIR(xa, xb)                                                                                              \
+        {                                                                                                          \
+            const bool first = c == cur.c0;                                                                        \
+            stage(kindQ, xa, tA, LAMBDA() { if (!first) flush_q(tB); },                                            \
+                  LAMBDA(int g) { if (!first && g >= 1 && g <= 4) q_epilogue(tB, c - 1, g - 1); });                \
+            stage(kindQ, xb, tB, LAMBDA() { flush_q(tA); }, LAMBDA(int g) { if (g >= 1 && g <= 4) q_epilogue(tA, c, g - 1); }); \
         }
-        if (HAS_KV) {
-            // head 0: the K stage carries the epilogue of the last query chunk (if any), the V stage the K' ride only
-            stage(kindKV, x0, tA, LAMBDA() { if (HAS_Q) flush_q(tB); }, LAMBDA(int g) { if (HAS_Q && g >= 1 && g <= 4) q_epilogue(tB, 7, g - 1); });
+        if (HAS_Q && !HAS_KV) {
+            // ---- query chunks only (the q-only kernel): two chunks per iteration
+            int c = cur.c0;
+            for (; c + 2 < cur.c1; c += 2) QPAIR(x0, x0)
+            QPAIR(x1, x2)
+            flush_q(tB);
+            __builtin_amdgcn_sched_barrier(0);
+            split_one(14);
+            split_one(15);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) q_epilogue(tB, cur.c1 - 1, a);
+        } else if (HAS_KV) {
+            // ---- (query chunks, then) heads
+            if (HAS_Q && has_q)
+                for (int c = cur.c0; c < cur.c1; c += 2) QPAIR(x0, x0)
+            // first head: its K stage carries the epilogue of the last query chunk (if the item has any), its V stage the K' ride
+            stage(kindKV, x0, tA, LAMBDA() { if (HAS_Q && has_q) flush_q(tB); },
+                  LAMBDA(int g) { if (HAS_Q && has_q && g >= 1 && g <= 4) q_epilogue(tB, cur.c1 - 1, g - 1); });
             stage(kindKV, x0, tB, LAMBDA() { flush_kv(tA); }, LAMBDA(int g) { ride_after_k(tA, 0, false, g); });
-            for (int h = 1; h < SCREAM_NHEAD - 1; ++h) {
+            for (int h = cur.h0 + 1; h < cur.h1 - 1; ++h) {
                 stage(kindKV, x0, tA, LAMBDA() { flush_kv(tB); }, LAMBDA(int g) { ride_after_v(tB, g); });               // K_h | V_{h-1}: planes, K'^T V
                 stage(kindKV, x0, tB, LAMBDA() { flush_kv(tA); }, LAMBDA(int g) { ride_after_k(tA, h - 1, true, g); });  // V_h | K'_h; head h - 1 out
             }
-            stage(kindKV, x1, tA, LAMBDA() { flush_kv(tB); }, LAMBDA(int g) { ride_after_v(tB, g); });                   // K_7: requests the next rows
-            stage(kindKV, x2, tB, LAMBDA() { flush_kv(tA); }, LAMBDA(int g) { ride_after_k(tA, SCREAM_NHEAD - 2, true, g); });  // V_7: splits them in place
+            stage(kindKV, x1, tA, LAMBDA() { flush_kv(tB); }, LAMBDA(int g) { ride_after_v(tB, g); });                   // the item's last head
+            stage(kindKV, x2, tB, LAMBDA() { flush_kv(tA); }, LAMBDA(int g) { ride_after_k(tA, cur.h1 - 2, true, g); });
             flush_kv(tB);
-        } else {
-            flush_q(tB);
-        }
-#undef LAMBDA
-        // ---- tile end, in the open: the last chunk's epilogue, and the two x steps the last MFMA groups were still using ----
-        __builtin_amdgcn_sched_barrier(0);
-        split_one(14);
-        split_one(15);
-        if (HAS_KV) {
+            // item end, in the open: the two x steps the last MFMA groups were still using, and the last head's K'^T V
+            __builtin_amdgcn_sched_barrier(0);
+            split_one(14);
+            split_one(15);
 #pragma unroll
             for (int g = 0; g < 11; ++g) ride_after_v(tB, g);
-            lds_only_barrier();  // every wave has read head 6's tiles (top of its last stage)
+            lds_only_barrier();  // every wave has read the previous head's tiles (top of its last stage)
             xch_write();
             lds_only_barrier();
-            xch_sum_store(SCREAM_NHEAD - 1);
-        } else {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) q_epilogue(tB, 7, a);
+            xch_sum_store(cur.h1 - 1);
         }
+#undef QPAIR
+#undef LAMBDA
         __builtin_amdgcn_sched_barrier(0);
         if (!has_next) break;
-        tile = tile_next;
+        ++item_no;
+        cur = nxt;
+        nxt = item_of(item_no + 1);
+        pos = 0;
     }
     VM_WAIT(0);  // the ring's last two stages (requested past the end) must have landed before the LDS is released
 }
@@ -393,7 +453,9 @@ extern "C" int scream_proj_x3_f32(const float* x, const void* proj_image, int32_
     const int64_t tiles = M / SCREAM_ROW_TILE;
     if (tiles == 0) return 0;
     SCREAM_REQUIRE(tiles < (1ll << 31), SCREAM_EUNSUPPORTED);
-    const dim3 grid(tiles < T_MAX_GRID ? (unsigned)tiles : (unsigned)T_MAX_GRID), block(TT);
+    // fewer tiles than CUs: every tile goes out in parts (3 for q|k|v, 2 otherwise), see the kernel
+    const int64_t items = tiles * ((has_q && has_kv) ? 3 : 2);
+    const dim3 grid(tiles >= T_MAX_GRID ? (unsigned)T_MAX_GRID : (unsigned)(items < T_MAX_GRID ? items : T_MAX_GRID)), block(TT);
     const __bf16* img = reinterpret_cast<const __bf16*>(proj_image);
     hipStream_t st = as_stream(stream);
     if (has_q && has_kv) proj_x3_kernel<true, true><<<grid, block, 0, st>>>(x, img, Q, kv_partial, tile_cloud, cloud_row0, cloud_len, row_base, (int)tiles);

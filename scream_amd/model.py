@@ -100,8 +100,8 @@ class PointTransformer(nn.Module):
     # falls back to attn_apply + merge GEMM + (fused or two-launch) FFN
     fused_tail = os.environ.get("SCREAM_FUSED_TAIL", "1") != "0"
     # fused tail only, OFF by default: the q/k/v projections on the ring-design kernel (csrc/proj_x3.hip) instead of the 8-wave
-    # split GEMM.  Same results to rounding; measured 0.6-1 % slower per step (its 128-row work items quantise worse over the
-    # 256 CUs and its elu / split rides do not hide under the MFMAs of a lone wave).  SCREAM_RING_PROJ=1.
+    # split GEMM.  Same results to rounding; measured 0.6 % slower per step (its elu / split rides do not hide under the MFMAs of
+    # a lone wave).  SCREAM_RING_PROJ=1.
     ring_proj = os.environ.get("SCREAM_RING_PROJ", "0") != "0"
 
     def _signature(self):
