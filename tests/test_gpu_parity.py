@@ -324,6 +324,29 @@ def test_forward_vs_reference_golden(golden, backend):
                                    err_msg="case seed=%d" % seed)
 
 
+@pytest.mark.parametrize("variant", ["ring_proj", "no_fused_tail", "no_fused_tail_no_fused_ffn"])
+def test_forward_every_split_path_variant_vs_reference_golden(golden, variant):
+    """The split-bf16 forward has one default path (8-wave projection GEMM + one-launch layer tail) and three selectable ones:
+    the ring-design projection kernel (SCREAM_RING_PROJ / net.ring_proj), the unfused tail (SCREAM_FUSED_TAIL=0: attention
+    apply + merge GEMM + one-launch FFN) and the fully unfused chain (also SCREAM_FUSED_FFN=0).  Same arithmetic, different
+    kernels and summation orders: each reproduces the reference's outputs to the default path's tolerance and agrees with the
+    default path to fp32 rounding."""
+    g = golden("e2e")
+    for seed, ns, nc, n, m, explicit in g["cases"]:
+        center = dev(g["center_%d" % seed]) if explicit else None
+        outs = {}
+        for name in ("default", variant):
+            net = build_net(int(seed), int(ns), int(nc), "x3")
+            if name == "ring_proj":
+                net.ring_proj = True
+            elif name.startswith("no_fused_tail"):
+                net.fused_tail = False
+                net.fused_ffn = name == "no_fused_tail"
+            outs[name] = net(dev(g["src_%d" % seed]), dev(g["tgt_%d" % seed]), center, 1.0, False, False, None)[0]
+        np.testing.assert_allclose(outs[variant].cpu().numpy(), g["out_%d" % seed], rtol=2e-4, atol=5e-5, err_msg="case seed=%d" % seed)
+        torch.testing.assert_close(outs[variant], outs["default"], rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_forward_batched_equals_single_pair(backend):
     net = build_net(5, 2, 2, backend)
