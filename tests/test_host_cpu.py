@@ -394,6 +394,57 @@ def test_no_instruction_touches_a_register_whose_asm_load_is_pending(tmp_path):
         assert n_kernels == {"gemm_x3.hip": 12, "tail_x3.hip": 1, "proj_x3.hip": 3}[src]
 
 
+def test_the_static_checker_detects_what_it_is_there_for():
+    """tools/asm_inflight_check.py guards the build; these are its three detectors on hand-written snippets (the patterns that
+    were really seen in round 2), each with its fixed counterpart."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import asm_inflight_check as chk
+    lines = lambda text: [l for l in text.strip().splitlines()]
+    # (1) a pending asm-load destination copied before the counted wait
+    bad = lines("""
+        global_load_dwordx4 v[4:7], v0, s[2:3]
+        global_load_lds_dwordx4 v[8:9], off
+        v_accvgpr_write_b32 a1, v5
+        s_waitcnt vmcnt(1)
+        v_add_f32_e32 v9, v4, v5
+    """)
+    assert [b[1] for b in chk.check_kernel("k", bad)] == ["v_accvgpr_write_b32 a1, v5"]
+    good = lines("""
+        global_load_dwordx4 v[4:7], v0, s[2:3]
+        global_load_lds_dwordx4 v[8:9], off
+        s_waitcnt vmcnt(1)
+        v_accvgpr_write_b32 a1, v5
+    """)
+    assert not chk.check_kernel("k", good)
+    acc = lines("""
+        global_load_dwordx4 a[0:3], v0, s[2:3]
+        v_accvgpr_read_b32 v9, a2
+        s_waitcnt vmcnt(0)
+    """)
+    assert len(chk.check_kernel("k", acc)) == 1   # loads into accumulation registers are tracked as well
+    # (2) a scalar base restored by a VALU instruction right in front of the memory instruction that uses it
+    hz = lines("""
+        v_readlane_b32 s1, v255, 19
+        global_store_dwordx4 v240, v[60:63], s[0:1]
+    """)
+    assert len(chk.check_scalar_base_hazard("k", hz)) == 1
+    ok = lines("""
+        v_readlane_b32 s1, v255, 19
+        s_nop 4
+        global_store_dwordx4 v240, v[60:63], s[0:1]
+    """)
+    assert not chk.check_scalar_base_hazard("k", ok)
+    assert not chk.check_scalar_base_hazard("k", lines("s_add_u32 s0, s4, 16\nglobal_load_dwordx4 v[4:7], v0, s[0:1]"))  # SALU: no hazard
+    # (3) the data of a wide store overwritten in the next cycle
+    sd = lines("""
+        global_store_dwordx4 v240, v[0:3], s[0:1]
+        v_accvgpr_read_b32 v1, a156
+    """)
+    assert len(chk.check_store_data_hazard("k", sd)) == 1
+    assert not chk.check_store_data_hazard("k", lines("global_store_dwordx4 v240, v[0:3], s[0:1]\ns_nop 1\nv_mov_b32_e32 v1, 0"))
+    assert not chk.check_store_data_hazard("k", lines("global_store_dword v240, v1, s[0:1]\nv_mov_b32_e32 v1, 0"))  # 32-bit data: none
+
+
 def test_f32_kernel_k_loop_has_no_register_spills(tmp_path):
     """gemm_f32.hip (the non-default SCREAM_GEMM=f32 path) is built at 2 blocks per CU = 128 VGPRs + 128 accumulators, and
     hipcc parks a handful of LOOP INVARIANTS (tile bookkeeping, epilogue pointers) in scratch: 6-18 dwords per
