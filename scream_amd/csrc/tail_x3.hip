@@ -333,6 +333,143 @@ __device__ __forceinline__ constexpr int xadd_slot(int h, int g) {
     return -1;
 }
 
+// ---- T_MFMA16 (build option, SCREAM_TAIL_MFMA16=1; off by default): the tail kernel on v_mfma_f32_16x16x32_bf16 -----------
+// A pure MFMA stream of the 16x16x32 shape sustains 12 % more flops at the socket power cap than the 32x32x16 one
+// (tools/ubench/mfma_energy.py).  In this kernel it does not pay: same results to rounding (the whole GPU suite passes on
+// it), the clock goes from 1.86 to 2.19 GHz, but the stages take 17 % more cycles (two accumulator tiles per step instead of
+// one: half the distance between dependent MFMAs, 16-cycle MFMAs hide half as many ride instructions) and a launch costs the
+// same joules -- 1.729 vs 1.742 ms per 333 k-row launch, 2.28 J both (profiles/r02_tail_mfma16_vs_32.txt).
+// The kernel keeps its data layouts -- fragment-major activations in HBM, "lane = row r of 32, lane half = features + 4" in
+// the VALU code (E form) -- and changes form only around the MFMAs:
+//   * B operand of a 16x16x32: lane (n = l & 15, kgroup = l >> 4) holds 8 contraction values of row n of a 16-row sub-tile.
+//     Two E-form plane registers R0, R1 (the two 16-deep steps of a 32-wide block) become the operands of the two sub-tiles
+//     with ONE v_permlane16_swap per dword: X0 = [R0.q0 R1.q0 R0.q2 R1.q2] (rows 0-15), X1 = [R0.q1 R1.q1 R0.q3 R1.q3].
+//   * its result (lane (n, q): 4 registers = output rows 4q + i of a 16 x 16 tile) comes back to the E form by the same swap
+//     between the two sub-tiles' registers; which output feature sits where is a fixed permutation baked into the weight
+//     images (pack_tail_kernel, kv_finalize_x3_kernel), as the contraction order is (tools/ubench/mfma16_layout.hip).
+// A step g of a stage (3 fragment reads, 192 cycles of MFMAs) is unchanged in shape: 12 MFMAs (2 sub-tiles x 6 products) on
+// the fragment of (32-deep block, 16-feature half) instead of 6 on (16-deep step, 32 features).
+#ifndef T_MFMA16
+#define T_MFMA16 0
+#endif
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// feature (0 .. 15) of a 16-feature half that row m of the A operand must carry so that the swapped-back accumulator is in
+// the layout convention (register 4a + b of lane half h = feature 8a + 4h + b of the 32-block)
+__host__ __device__ __forceinline__ int perm16(int m) { return (m & 3) | ((m & 4) << 1) | ((m & 8) >> 1); }
+// contraction index (0 .. 31) that element j of lane group kg of a swapped B operand holds
+__host__ __device__ __forceinline__ int k_of16(int kg, int j) { return chunk_k(kg & 1, kg >> 1, j); }
+
+// v_permlane16_swap_b32 as an asm statement: through __builtin_amdgcn_permlane16_swap hipcc 7.2 folded sixteen swaps of
+// lane-affine values into three and copied the results around (tools/ubench/swap_rt.hip: every component became component 0
+// of the partner row).  Two swaps per statement; two wait states in front (a VALU result feeding a permlane swap) and
+// behind (its results feeding a VALU or matrix instruction) -- hipcc pads neither side of an asm statement.
+__device__ __forceinline__ void swap16x2(unsigned& a0, unsigned& a1, unsigned& b0, unsigned& b1) {
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %2\n\t"
+                 "v_permlane16_swap_b32 %1, %3\n\t"
+                 "s_nop 1"
+                 : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+}
+__device__ __forceinline__ void swap16x4(unsigned& a0, unsigned& a1, unsigned& a2, unsigned& a3, unsigned& b0, unsigned& b1,
+                                         unsigned& b2, unsigned& b3) {  // (two statements of two: eight tied registers at once made hipcc
+    swap16x2(a0, a1, b0, b1);                                            //  park pending load destinations elsewhere)
+    swap16x2(a2, a3, b2, b3);
+}
+// (R0, R1) <-> (X0, X1) for the three planes of a 32-deep block (an involution)
+__device__ __forceinline__ void swap_planes(bf16x8 (&a)[3], bf16x8 (&b)[3]) {
+    if (!T_MFMA16) return;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        u32x4_t ua = __builtin_bit_cast(u32x4_t, a[p]), ub = __builtin_bit_cast(u32x4_t, b[p]);
+        unsigned x0 = ua[0], x1 = ua[1], x2 = ua[2], x3 = ua[3], y0 = ub[0], y1 = ub[1], y2 = ub[2], y3 = ub[3];
+        swap16x4(x0, x1, x2, x3, y0, y1, y2, y3);
+        ua = u32x4_t{x0, x1, x2, x3};
+        ub = u32x4_t{y0, y1, y2, y3};
+        a[p] = __builtin_bit_cast(bf16x8, ua);
+        b[p] = __builtin_bit_cast(bf16x8, ub);
+    }
+}
+__device__ __forceinline__ void swap_f4(float& a0, float& a1, float& a2, float& a3, float& b0, float& b1, float& b2, float& b3) {
+    unsigned x0 = __builtin_bit_cast(unsigned, a0), x1 = __builtin_bit_cast(unsigned, a1), x2 = __builtin_bit_cast(unsigned, a2),
+             x3 = __builtin_bit_cast(unsigned, a3), y0 = __builtin_bit_cast(unsigned, b0), y1 = __builtin_bit_cast(unsigned, b1),
+             y2 = __builtin_bit_cast(unsigned, b2), y3 = __builtin_bit_cast(unsigned, b3);
+    swap16x4(x0, x1, x2, x3, y0, y1, y2, y3);
+    a0 = __builtin_bit_cast(float, x0); a1 = __builtin_bit_cast(float, x1); a2 = __builtin_bit_cast(float, x2); a3 = __builtin_bit_cast(float, x3);
+    b0 = __builtin_bit_cast(float, y0); b1 = __builtin_bit_cast(float, y1); b2 = __builtin_bit_cast(float, y2); b3 = __builtin_bit_cast(float, y3);
+}
+// a 32 x 32 accumulator tile between the E form and the four 16 x 16 tiles (sub-tile, feature half) at registers
+// 4 (2 fb + sub) .. + 3; also a 4 x f32x4 segment of x or Q' (same register numbering)
+__device__ __forceinline__ void swap_tile(f32x16& t) {
+    if (!T_MFMA16) return;
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+        float a0 = t[8 * fb], a1 = t[8 * fb + 1], a2 = t[8 * fb + 2], a3 = t[8 * fb + 3];
+        float b0 = t[8 * fb + 4], b1 = t[8 * fb + 5], b2 = t[8 * fb + 6], b3 = t[8 * fb + 7];
+        swap_f4(a0, a1, a2, a3, b0, b1, b2, b3);
+        t[8 * fb] = a0; t[8 * fb + 1] = a1; t[8 * fb + 2] = a2; t[8 * fb + 3] = a3;
+        t[8 * fb + 4] = b0; t[8 * fb + 5] = b1; t[8 * fb + 6] = b2; t[8 * fb + 7] = b3;
+    }
+}
+__device__ __forceinline__ void swap_seg(f32x4 (&x)[4]) {
+    if (!T_MFMA16) return;
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+        float a0 = x[2 * fb][0], a1 = x[2 * fb][1], a2 = x[2 * fb][2], a3 = x[2 * fb][3];
+        float b0 = x[2 * fb + 1][0], b1 = x[2 * fb + 1][1], b2 = x[2 * fb + 1][2], b3 = x[2 * fb + 1][3];
+        swap_f4(a0, a1, a2, a3, b0, b1, b2, b3);
+        x[2 * fb] = f32x4{a0, a1, a2, a3};
+        x[2 * fb + 1] = f32x4{b0, b1, b2, b3};
+    }
+}
+
+// One step of a stage: acc (32 features x 32 rows) += W fragment . operand, six products.  32x32x16: w = the fragment of 16-deep
+// step `sel` of the block, operand = (sel ? b1 : b0).  16x16x32: w = the fragment of feature half `sel` over the whole 32-deep
+// block, operands b0 / b1 = the two row sub-tiles (swap_planes), results into the tiles (sub, sel).
+template <int NV = 0>
+__device__ __forceinline__ void mfma_step(f32x16& acc, const bf16x8 (&w)[3], const bf16x8 (&b0)[3], const bf16x8 (&b1)[3], int sel,
+                                          bool zero = false) {
+#if T_MFMA16
+    f32x4 d0, d1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        d0[i] = zero ? 0.f : acc[8 * sel + i];
+        d1[i] = zero ? 0.f : acc[8 * sel + 4 + i];
+    }
+#define M16(D, A, B) D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, D, 0, 0, 0)
+    M16(d0, w[0], b0[2]); M16(d1, w[0], b1[2]);
+    M16(d0, w[1], b0[1]); M16(d1, w[1], b1[1]);
+    M16(d0, w[2], b0[0]); M16(d1, w[2], b1[0]);
+    M16(d0, w[0], b0[1]); M16(d1, w[0], b1[1]);
+    M16(d0, w[1], b0[0]); M16(d1, w[1], b1[0]);
+    M16(d0, w[0], b0[0]); M16(d1, w[0], b1[0]);
+#undef M16
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc[8 * sel + i] = d0[i];
+        acc[8 * sel + 4 + i] = d1[i];
+    }
+    if (NV >= 0) {  // first MFMA, the three prefetch reads of the next fragment group, the other eleven MFMAs (with ride slots)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        if (NV == 0) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 11; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x002, (NV + 1) / 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x002, (NV + 1) / 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+    if (NV >= 0) mfma6<(NV > 0 ? NV : 0)>(acc, w, sel ? b1 : b0, zero);
+    else mfma6_free(acc, w, sel ? b1 : b0, zero);
+#endif
+}
+
 __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict__ Q,      // fragment-major [M, 256]
                                                         const char* __restrict__ kvimg,   // [n_clouds][KV_IMAGE_BYTES]
                                                         const int32_t* __restrict__ tile_cloud, int kv_cloud_offset,
@@ -434,15 +571,18 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         if (T_ABLATE & 16) {
             const f32x4 f = {(float)lane, 1.0f, 0.5f, (float)tile_tag};
             split3(f, f, qp[s2][0], qp[s2][1], qp[s2][2]);
+            if (s2 == 1) swap_planes(qp[0], qp[1]);
             return;
         }
         split3(qb[2 * s2], qb[2 * s2 + 1], qp[s2][0], qp[s2][1], qp[s2][2]);
+        if (s2 == 1) swap_planes(qp[0], qp[1]);
     };
     auto apply_mfma = [&](int s2) {
         bf16x8 w[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) w[p] = __builtin_bit_cast(bf16x8, op.kv[p * 2 + s2]);
-        mfma6_free(aT, w, qp[s2], s2 == 0);
+        mfma_step<-1>(aT, w, qp[0], qp[1], s2, T_MFMA16 ? true : s2 == 0);
+        if (s2 == 1) swap_tile(aT);  // back to the E form for the scaling and the split
     };
     auto apply_z = [&](f32x4 (&qb)[4]) {  // Z = 1 / (Q'.Ksum + 1e-6); lanes r and r + 32 share row r
         float zp = 0.f;
@@ -465,6 +605,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             ap[s2][1][j + e] = b;
             ap[s2][2][j + e] = (__bf16)(r1 - (float)b);
         }
+        if (k == 7) swap_planes(ap[0], ap[1]);
     };
     // the pieces of one apply as they ride in group g of a 16-group stage: operands consumed in groups 0-3
     auto apply_ride = [&](f32x4 (&qb)[4], int g, bf16x8 (&ap)[2][3], float S, int tile_tag) {
@@ -547,6 +688,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             f32x4 (&x_req)[4] = (h & 1) ? xs2 : xs;    // segment h
             if (h > 0) {
                 pin_x(x_prev);
+                swap_seg(x_prev);  // (16x16x32: the accumulators are in the MFMA's form while they accumulate)
                 if (RIDE) {
                     pin_head(op);
                     pin_x(q_cons);
@@ -585,7 +727,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                     const int pc = xadd_slot(h, g);
                     if (pc >= 0 && !(T_ABLATE & 1024)) add_x4(acc[h > 0 ? h - 1 : 0], x_prev, pc);
                 }
-                mfma6<(h > 0 ? 6 : 0)>(acc[g >> 1], wf[g % T_PF], ap[g & 1], h == 0 && (g & 1) == 0);
+                mfma_step<(h > 0 ? 6 : 0)>(acc[g >> 1], wf[g % T_PF], ap[0], ap[1], g & 1, h == 0 && (T_MFMA16 || (g & 1) == 0));
             }
             ++q;
         };
@@ -593,11 +735,12 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         constexpr std::integral_constant<bool, false> no{};
 #define HEAD(n) std::integral_constant<int, n>{}
         auto flush_none = [&]() {};
-        auto flush_mergeA = [&]() { mfma6_free(acc[7], wfd, apA[1]); };  // deferred group of a merge stage of an even head
-        auto flush_mergeB = [&]() { mfma6_free(acc[7], wfd, apB[1]); };
+        auto flush_mergeA = [&]() { mfma_step<-1>(acc[7], wfd, apA[0], apA[1], 1); };  // deferred group of a merge stage of an even head
+        auto flush_mergeB = [&]() { mfma_step<-1>(acc[7], wfd, apB[0], apB[1], 1); };
+        auto flush_mergeA0 = [&]() { mfma_step<-1>(acc[7], wfd, apA[0], apA[1], 1, T_MFMA16 != 0); };  // ... of stage 0 (16x16x32: its tiles start there)
         //            head   planes  planes of head + 1   Q' consumed (head + 1)   Q' requested (head + 2)   deferred group of
         stage_merge(HEAD(0), apA, apB, qB, qA, flush_none);   // (the previous tile ended flushed)
-        stage_merge(HEAD(1), apB, apA, qA, qB, flush_mergeA);
+        stage_merge(HEAD(1), apB, apA, qA, qB, flush_mergeA0);
         stage_merge(HEAD(2), apA, apB, qB, qA, flush_mergeB);
         stage_merge(HEAD(3), apB, apA, qA, qB, flush_mergeA);
         stage_merge(HEAD(4), apA, apB, qB, qA, flush_mergeB);
@@ -607,7 +750,10 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         flush_mergeB();  // norm1 needs the finished accumulators
         VM_WAIT(12);     // x segment 7 (requested at the top of stage 7, older than that stage's twelve weight pieces)
         pin_x(xs2);
+        swap_seg(xs2);
         add_x(acc[7], xs2);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) swap_tile(acc[b]);  // the norm works on the E form
 
         TSTAMP(1);  // end of the merge phase
         // ---- m1 = LayerNorm1(merge + x) (models/transformer.py:84), straight into the B-operand planes of FFN-up ---
@@ -645,6 +791,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                         for (int k = 0; k < 4; ++k) v[a2][k] = acc[b][4 * a + k] * rstd * g4[k] + b4[k];
                     }
                     split3(v[0], v[1], mp[2 * b + s2][0], mp[2 * b + s2][1], mp[2 * b + s2][2]);
+                    if (s2 == 1) swap_planes(mp[2 * b], mp[2 * b + 1]);
                 }
         }
 
@@ -664,6 +811,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 hout[s2][1][j + e] = b;
                 hout[s2][2][j + e] = (__bf16)(r1 - (float)b);
             }
+            if (k == 7) swap_planes(hout[0], hout[1]);
         };
         // XLOAD: x segment to request in this stage (-1: none)
         auto stage_up = [&](auto first, auto xload, auto flush) {
@@ -689,7 +837,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                         (g + T_PF - 1 == 15 ? wfd[p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag(wb + (p * 16 + g + T_PF - 1) * 1024);
                 }
                 if (g < 12) dma_piece(q + 2, g);
-                mfma6(hT, wf[g % T_PF], mp[g], g == 0);
+                mfma_step(hT, wf[g % T_PF], mp[g & ~1], mp[g | 1], g & 1, T_MFMA16 ? g < 2 : g == 0);
             }
             ++q;
         };
@@ -705,12 +853,14 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
             __builtin_amdgcn_sched_barrier(0);
             if (XADD == 0) {  // the tile's first down stage starts the accumulators: tile 0 from its x segment, the others from 0
                 pin_x(xs);
+                swap_seg(xs);
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) acc[0][4 * a + k] = (T_ABLATE & 16) ? 1.0f : xs[a][k];
             } else if (XADD > 0) {
                 pin_x(xs);
+                swap_seg(xs);
                 add_x(acc[XADD > 0 ? XADD : 0], xs);
             }
             if (RIDE == 2) {  // (untouched registers when the block has no next tile: the results are never used)
@@ -730,6 +880,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
 #pragma unroll
                 for (int p = 0; p < 3; ++p) wf[g0][p] = ld_frag(wb + (p * 16 + g0) * 1024);
             flush();
+            if (decltype(with_split)::value) swap_tile(hT);  // (16x16x32: the relu / split below reads the E form)
 #pragma unroll
             for (int g = 0; g < 15; ++g) {  // g = blk * 2 + s2; group 15 (acc[7] += wfd . hin[1]) is deferred to the next stage
                 if (g + T_PF - 1 < 16) {
@@ -751,7 +902,7 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
                 }
                 if (RIDE == 2) apply_ride(qA, g, apA, S_next, tile_next);
                 if (decltype(with_split)::value && (g & 1) == 0) split_pair(g >> 1, hout);
-                mfma6(acc[g >> 1], wf[g % T_PF], hin[g & 1], XADD == 0 && g >= 2 && (g & 1) == 0);
+                mfma_step(acc[g >> 1], wf[g % T_PF], hin[0], hin[1], g & 1, XADD == 0 && g >= 2 && (T_MFMA16 || (g & 1) == 0));
             }
             ++q;
         };
@@ -760,19 +911,21 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
         // stage order (= image order): W1_0 | W1_c, W2_{c-1} for c = 1 .. 31 | W2_31.  The norm2 residual: the up stage of
         // chunk c requests x segment c - 1, the down stage of chunk c - 1 that follows adds it (c - 1 < 8) -- the first
         // four pair iterations are peeled so that every accumulator index is a compile-time constant.
-        auto flush_up = [&]() { mfma6_free(hT, wfd, mp[15]); };          // deferred group of an up stage
-        auto flush_downA = [&]() { mfma6_free(acc[7], wfd, hpA[1]); };   // ... of a down stage whose operand was hpA
-        auto flush_downB = [&]() { mfma6_free(acc[7], wfd, hpB[1]); };
+        auto flush_up = [&]() { mfma_step<-1>(hT, wfd, mp[14], mp[15], 1); };            // deferred group of an up stage
+        auto flush_downA = [&]() { mfma_step<-1>(acc[7], wfd, hpA[0], hpA[1], 1); };     // ... of a down stage whose operand was hpA
+        auto flush_downB = [&]() { mfma_step<-1>(acc[7], wfd, hpB[0], hpB[1], 1); };
+        auto flush_downA0 = [&]() { mfma_step<-1>(acc[7], wfd, hpA[0], hpA[1], 1, T_MFMA16 != 0); };  // ... of the tile's first down stage
         stage_up(yes, none, flush_none);
         flush_up();
+        swap_tile(hT);
 #pragma unroll
         for (int k = 0; k < 8; ++k) split_pair(k, hpA);
-#define PAIR(c, fl)                                                                         \
+#define PAIR(c, fl, flA)                                                                    \
         stage_up(no, HEAD((c) - 1), fl);                           /* chunk c */             \
         stage_down(hpA, hpB, yes, HEAD((c) - 1), ride0, flush_up); /* chunk c - 1, splits c */ \
-        stage_up(no, HEAD(c), flush_downA);                        /* chunk c + 1 */         \
+        stage_up(no, HEAD(c), flA);                                /* chunk c + 1 */         \
         stage_down(hpB, hpA, yes, HEAD(c), ride0, flush_up);       /* chunk c, splits c + 1 */
-        PAIR(1, flush_none) PAIR(3, flush_downB) PAIR(5, flush_downB) PAIR(7, flush_downB)
+        PAIR(1, flush_none, flush_downA0) PAIR(3, flush_downB, flush_downA) PAIR(5, flush_downB, flush_downA) PAIR(7, flush_downB, flush_downA)
 #undef PAIR
         for (int c = 9; c < 31; c += 2) {
             stage_up(no, none, flush_downB);
@@ -800,6 +953,8 @@ __global__ __launch_bounds__(TT, 1) void tail_x3_kernel(const float* __restrict_
 
         TSTAMP(4);  // after the open apply of the next tile's head 1
         // ---- y = LayerNorm2(x + ffn) (the residual is already in the accumulators), stored fragment-major ------------
+#pragma unroll
+        for (int b = 0; b < 8; ++b) swap_tile(acc[b]);  // (16x16x32: back to the E form)
         {
             float sum = 0.f;
 #pragma unroll
@@ -887,20 +1042,29 @@ __global__ void pack_tail_kernel(const float* __restrict__ Wm, const float* __re
     if (t >= TAIL_STAGES * 16 * 64) return;
     const int lane = t & 63, frag = (t >> 6) & 15, stage = t >> 10;
     const int m = lane & 31, half = lane >> 5;
+    // T_MFMA16: fragment (block frag >> 1, feature half frag & 1): lane (m16, kg) carries output feature 16 fb + perm16(m16)
+    // and contraction indices k_of16(kg, 0 .. 7) of the 32-deep block
+    const int fb = frag & 1, f16 = 16 * fb + perm16(lane & 15), kg = lane >> 4;
     float v[8];
     if (stage < 8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = Wm[(int64_t)(32 * (frag >> 1) + m) * 256 + 32 * stage + chunk_k(frag & 1, half, j)];
+        for (int j = 0; j < 8; ++j)
+            v[j] = T_MFMA16 ? Wm[(int64_t)(32 * (frag >> 1) + f16) * 256 + 32 * stage + k_of16(kg, j)]
+                            : Wm[(int64_t)(32 * (frag >> 1) + m) * 256 + 32 * stage + chunk_k(frag & 1, half, j)];
     } else {
         const int st = stage - 8;
         const bool up = st == 0 || (st < 63 && (st & 1));
         const int c = st == 0 ? 0 : st == 63 ? 31 : up ? (st + 1) / 2 : st / 2 - 1;
         if (up) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = W1[(int64_t)(32 * c + m) * 256 + 32 * (frag >> 1) + chunk_k(frag & 1, half, j)];
+            for (int j = 0; j < 8; ++j)
+                v[j] = T_MFMA16 ? W1[(int64_t)(32 * c + f16) * 256 + 32 * (frag >> 1) + k_of16(kg, j)]
+                                : W1[(int64_t)(32 * c + m) * 256 + 32 * (frag >> 1) + chunk_k(frag & 1, half, j)];
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = W2[(int64_t)(32 * (frag >> 1) + m) * 1024 + 32 * c + chunk_k(frag & 1, half, j)];
+            for (int j = 0; j < 8; ++j)
+                v[j] = T_MFMA16 ? W2[(int64_t)(32 * (frag >> 1) + f16) * 1024 + 32 * c + k_of16(kg, j)]
+                                : W2[(int64_t)(32 * (frag >> 1) + m) * 1024 + 32 * c + chunk_k(frag & 1, half, j)];
         }
     }
     bf16x8 p0, p1, p2;
@@ -947,7 +1111,10 @@ __global__ __launch_bounds__(1024) void kv_finalize_x3_kernel(const float* __res
             const float r1 = x - (float)a;
             const __bf16 b = (__bf16)r1;
             const __bf16 cc = (__bf16)(r1 - (float)b);
-            __bf16* base = reinterpret_cast<__bf16*>(img) + ((size_t)(h * 3) * 2 + s2) * 512 + (v + 32 * hf) * 8 + j;
+            // T_MFMA16: fragment = value half v >> 4, lane = (kg = s2 + 2 hf, m16 = perm16(v & 15)) -- d = k_of16(kg, j)
+            __bf16* base = reinterpret_cast<__bf16*>(img) +
+                           (T_MFMA16 ? ((size_t)(h * 3) * 2 + (v >> 4)) * 512 + (16 * (s2 + 2 * hf) + perm16(v & 15)) * 8 + j
+                                     : ((size_t)(h * 3) * 2 + s2) * 512 + (v + 32 * hf) * 8 + j);
             base[0] = a;
             base[2 * 512] = b;
             base[4 * 512] = cc;

@@ -364,8 +364,10 @@ def test_no_instruction_touches_a_register_whose_asm_load_is_pending(tmp_path):
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import asm_inflight_check as chk
     for src, extra, want in (("gemm_x3.hip", [], "gemm_x3_kernel"), ("tail_x3.hip", ["-ffp-contract=off"], "tail_x3_kernel"),
-                             ("proj_x3.hip", ["-ffp-contract=off"], "proj_x3_kernel")):
-        out = tmp_path / (src + ".s")
+                             ("proj_x3.hip", ["-ffp-contract=off"], "proj_x3_kernel"),
+                             # the 16x16x32 build option of the layer tail (SCREAM_TAIL_MFMA16=1): same guards, scratch allowed
+                             ("tail_x3.hip", ["-ffp-contract=off", "-DT_MFMA16=1"], "tail_x3_kernel")):
+        out = tmp_path / (src + ("16" if "-DT_MFMA16=1" in extra else "") + ".s")
         subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-S", "--cuda-device-only", *extra, "-o", str(out),
                         os.path.join(REPO, "scream_amd", "csrc", src)], check=True, capture_output=True, timeout=900)
         n_kernels = 0
@@ -383,7 +385,7 @@ def test_no_instruction_touches_a_register_whose_asm_load_is_pending(tmp_path):
             # ... nor does a VALU instruction overwrite the data registers of a wide asm store right behind it (wrong dwords in
             # a quarter of the lanes, also round 2)
             assert not chk.check_store_data_hazard(name, body), name
-            if src in ("tail_x3.hip", "proj_x3.hip"):
+            if src in ("tail_x3.hip", "proj_x3.hip") and "-DT_MFMA16=1" not in extra:
                 # The layer tail keeps NO scratch: a spilled value that is reloaded inside a stage puts a vmcnt(0) in front
                 # of its use (hipcc cannot order a scratch reload against the LDS-DMA in flight) and drains the weight ring
                 # once per stage -- it did, for a 64-bit per-lane pointer, until every address became scalar base + lane offset.
