@@ -19,6 +19,11 @@ def run():
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = torch.randn(4096 * 8, device=dev, generator=g).to(torch.bfloat16)
     zero = torch.zeros(4096 * 8, device=dev, dtype=torch.bfloat16)
+    # fp16 operands as the 2-plane split makes them: leading plane = values scaled to ~2^11, second plane = their rounding residuals
+    v = torch.randn(4096 * 8, device=dev, generator=g) * 2048.0
+    h0 = v.to(torch.float16)
+    h1 = (v - h0.float()).to(torch.float16)
+    rnd_h = torch.where(torch.arange(4096 * 8, device=dev) % 16 < 8, h0, h1).view(torch.bfloat16)  # alternate 16-byte pieces
     out = torch.empty(256 * 256, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     samples, stop = [], [False]
@@ -34,7 +39,9 @@ def run():
     flop = 256 * 4 * iters * 64 * 2.0 * 32 * 32 * 16  # blocks x waves x iterations x instruction(-pair)s x flops
     print("%-34s %9s %9s %9s %10s %12s %9s" % ("variant", "ms", "sclk MHz", "power W", "J/launch", "pJ/flop(dyn)", "PFLOP/s"))
     for tag, data in (("random operands", rnd), ("zero operands", zero)):
-        for shape, name in ((0, "32x32x16"), (1, "16x16x32 (x2)")):
+        for shape, name in ((0, "32x32x16"), (1, "16x16x32 (x2)"), (2, "32x32x16 f16")):
+            if shape == 2 and tag.startswith("random"):
+                data = rnd_h
             call = lambda: lib.mfma_burn_launch(shape, data.data_ptr(), out.data_ptr(), iters, st)
             call(); torch.cuda.synchronize(); time.sleep(0.4)
             t0 = time.time(); n = 0
