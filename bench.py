@@ -19,10 +19,13 @@ Extra objects on that line:
                   on the launch streams inside the timed region (scream_trace_*).  The step's pairs run as two
                   concurrent lanes, so launches overlap: that time is the union of the launch intervals
                   ("busy_ms_per_step"; "summed_launch_ms_per_step" and the per-launch avg_ms rows count overlapped
-                  time twice and are what rocprofv3's per-kernel durations add up to; --lanes 1 makes them equal).  Peak (MI355X_MICROARCH.md): SCREAM_GEMM=x3 (default) runs
-                  gemm_x3_kernel on the bf16 matrix cores with six MFMAs per fp32 product -> 2500 / 6 = 416.7
-                  TFLOP/s of fp32-equivalent work; SCREAM_GEMM=f32 runs gemm_f32_kernel against the 157.3
-                  TFLOP/s fp32 matrix peak.
+                  time twice and are what rocprofv3's per-kernel durations add up to; --lanes 1 makes them equal).  Peak
+                  (MI355X_MICROARCH.md: 2500 TFLOP/s dense for bf16 and fp16 alike): SCREAM_GEMM=h2 (default) runs the split
+                  kernels on the fp16 matrix cores with THREE MFMAs per fp32 product -> 2500 / 3 = 833.3 TFLOP/s of
+                  fp32-equivalent work; SCREAM_GEMM=x3 on the bf16 matrix cores with six -> 2500 / 6 = 416.7;
+                  SCREAM_GEMM=f32 runs gemm_f32_kernel against the 157.3 TFLOP/s fp32 matrix peak.
+  sustained_value -- pairs/s over >= 3 s of back-to-back steps right after the timed region (the power governor needs a few
+                  hundred ms to settle; `value` is the K steps the driver asked for).
   variant_registered_pred -- the same step re-timed (outside the headline region) with src_pred replaced, after the
                   forward, by GT-registered src + 1 cm noise, so that the search/gather/Kabsch stages see realistic
                   correspondence counts (random weights leave almost none): pairs/s, mean K, fraction registered.
@@ -45,14 +48,15 @@ sys.path.insert(0, REPO)
 
 PAIRS_PER_GPU = 32
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
-PEAK_BF16_DENSE_TFLOPS = 2500.0  # same table; the split GEMM spends six bf16 MFMAs per fp32 product
-# context only, never `peak`: what a pure stream of v_mfma_f32_32x32x16_bf16 on random register operands sustains at the
-# 1400 W socket cap (tools/ubench/mfma_energy.py, profiles/r02_ubench_mfma_energy.txt: 1.84 PFLOP/s at 1.80 GHz)
-MEASURED_BF16_MFMA_AT_POWER_CAP_TFLOPS = 1840.0
+PEAK_16BIT_DENSE_TFLOPS = 2500.0  # same table, bf16 and fp16; the split kernels spend 3 (fp16 x 2) or 6 (bf16 x 3) MFMAs per fp32 product
+MFMAS_PER_PRODUCT = {"h2": 3, "x3": 6, "f32": 1}
+# context only, never `peak`: what a pure stream of v_mfma_f32_32x32x16_{bf16,f16} on random register operands sustains at
+# the 1400 W socket cap (tools/ubench/mfma_energy.py: profiles/r02_ubench_mfma_energy.txt 1.84 PFLOP/s bf16 at 1.80 GHz;
+# profiles/r03_ubench_mfma_energy.txt 1.63 PFLOP/s fp16 at 1.63 GHz on a box whose bf16 row read 1.76)
+MEASURED_MFMA_AT_POWER_CAP_TFLOPS = {"x3": 1840.0, "h2": 1627.0}
 GEMM_NAMES = {0: "gemm<EPI_NONE>", 1: "gemm<EPI_ELU1> (cross-layer q projection)",
               5: "gemm<EPI_QKV> (q/k/v projection + fused K^T V reduce)",
-              6: "ffn_x3_kernel (FFN 256->1024, relu, 1024->256 + residual + LayerNorm in one launch)",
-              7: "tail_x3_kernel (attention apply, merge + LayerNorm1, FFN + LayerNorm2 in one launch; N = 256 + 2 x 1024 columns)",
+              7: "tail_kernel (attention apply, merge + LayerNorm1, FFN + LayerNorm2 in one launch; N = 256 + 2 x 1024 columns)",
               2: "gemm<EPI_RELU> (FFN 256->1024)", 3: "gemm<EPI_BIAS_RELU> (coor_mlp)",
               4: "gemm<EPI_RES_LN> (merge, FFN 1024->256 + residual + LayerNorm)",
               100: "pe_embed_ln_kernel", 101: "kv_finalize_tiles_kernel", 102: "attn_apply_kernel",
@@ -218,6 +222,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per step per GPU")
     ap.add_argument("--lanes", type=int, default=2, help="concurrent sub-batches of the step's pairs (scream_amd/lanes.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sustain", dest="sustain", action="store_false", help="skip the >= 3 s sustained-rate leg")
     ap.add_argument("--no-power", action="store_true",
                     help="do not sample rocm-smi beside the variant steps (under rocprofv3 its preload has initialised the GPU in "
                          "this process, and starting another program from it is refused on the GPU boxes)")
@@ -361,6 +366,22 @@ def main():
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- sustained rate: >= 3 s of back-to-back steps (same step, no trace), the same count on every rank -------
+    n_sus = max(args.steps, int(np.ceil(3.0 / max(elapsed / max(args.steps, 1), 1e-4)))) if args.sustain else 0
+    sustained = None
+    if n_sus:
+        fence()
+        t_s = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        fence()
+        sus_elapsed = time.perf_counter() - t_s
+        if world > 1:
+            t = torch.tensor([sus_elapsed], device=coll_dev, dtype=torch.float64)
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+            sus_elapsed = float(t.item())
+        sustained = (round(B * world * n_sus / sus_elapsed, 3), n_sus, round(sus_elapsed, 3))
+
     # ---- the same step with realistic correspondence counts (outside the headline's timed region) -------------
     # rank 0 also samples the socket power and the shader clock beside it: the split GEMM runs at the 1400 W cap
     n_var = min(args.steps, 5)
@@ -427,7 +448,7 @@ def main():
         e = by.setdefault(kind[i], {"launches": 0, "ms": 0.0, "padded_flops": 0.0})
         e["launches"] += 1
         e["ms"] += ms[i]
-        e["padded_flops"] += 2.0 * mm[i] * nn[i] * kk[i] * (2 if kind[i] == 6 else 1)  # kind 6 = FFN up AND down
+        e["padded_flops"] += 2.0 * mm[i] * nn[i] * kk[i] 
         if kind[i] < 100:
             e2 = by_shape.setdefault((kind[i], mm[i], nn[i], kk[i]), {"launches": 0, "ms": 0.0})
             e2["launches"] += 1
@@ -447,34 +468,41 @@ def main():
         by_kernel.append(row)
     by_gemm_shape = [{"epilogue": k_[0], "M": int(k_[1]), "N": int(k_[2]), "K": int(k_[3]), "launches": v["launches"],
                       "avg_ms": round(v["ms"] / v["launches"], 4),
-                      "tflops_padded": round(2.0 * k_[1] * k_[2] * k_[3] * (2 if k_[0] == 6 else 1) / (v["ms"] / v["launches"] * 1e-3) / 1e12, 1)}
+                      "tflops_padded": round(2.0 * k_[1] * k_[2] * k_[3] / (v["ms"] / v["launches"] * 1e-3) / 1e12, 1)}
                      for k_, v in sorted(by_shape.items())]
 
-    x3 = net.gemm_backend == "x3"
-    fused = x3 and net.fused_tail
+    gb = net.gemm_backend
+    split_backend = gb in ("h2", "x3")
+    n_prod = MFMAS_PER_PRODUCT[gb]
+    fused = split_backend and net.fused_tail
     # ---- HBM traffic: algorithmic bytes computed here, counter bytes from the committed PMC record of this command
     algo_b = sum(activation_bytes_per_pair(n, m, fused)[0] for n, m in zip(src_len, tgt_len))
     design_b = sum(activation_bytes_per_pair(n, m, fused)[1] for n, m in zip(src_len, tgt_len))
-    weight_b = float(sum(p.numel() for p in net.parameters()) * (6 if x3 else 4))  # every weight image is read at least once per step
+    weight_b = float(sum(p.numel() for p in net.parameters()) * {"h2": 4, "x3": 6, "f32": 4}[gb])  # every weight image is read at least once per step
     trec, tpath = load_traffic_record()
     traffic = None
     if trec is not None:
-        dom = next((v for k_, v in trec["kernels"].items() if ("tail_x3_kernel" if fused else "gemm") in k_), None)
+        dom = next((v for k_, v in trec["kernels"].items() if ("tail_kernel" if fused else "gemm") in k_), None)
         per_launch_algo = None
-        if fused:  # the layer-tail kernel by itself: Q' + y per token and application (x is re-read from the projection's pass)
-            per_launch_algo = 2048.0 * sum(6 * (n + m) + 12 * n for n, m in zip(src_len, tgt_len)) / (18.0 * len(lane_parts))
+        if fused:  # the layer-tail kernel by itself: Q' + y per token and application (x is re-read from the projection's pass).
+            # Per launch AT THE LANE COUNT OF THE COUNTER RECORD (a launch covers 1 / lanes of the step's rows): like for like
+            per_launch_algo = 2048.0 * sum(6 * (n + m) + 12 * n for n, m in zip(src_len, tgt_len)) / (18.0 * trec.get("lanes", 1))
         traffic = {"counter_bytes_per_step": round(trec["hbm_bytes_per_step"] * B / PAIRS_PER_GPU),
                    "algorithmic_bytes_per_step": round(algo_b + weight_b), "design_bytes_per_step": round(design_b + weight_b),
                    "ratio": round(trec["hbm_bytes_per_step"] * B / PAIRS_PER_GPU / (algo_b + weight_b), 3),
                    "dominant_kernel_counter_bytes_per_launch": None if dom is None else round(dom["fetch_bytes_per_launch"] + dom["write_bytes_per_launch"]),
                    "dominant_kernel_algorithmic_bytes_per_launch": None if per_launch_algo is None else round(per_launch_algo),
+                   "dominant_kernel_ratio": None if (dom is None or per_launch_algo is None) else round((dom["fetch_bytes_per_launch"] + dom["write_bytes_per_launch"]) / per_launch_algo, 3),
+                   "lanes_of_counter_record": trec.get("lanes", 1), "gemm_backend_of_counter_record": trec.get("gemm_backend"),
                    "counters": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE, separate passes, %d lane(s)" % trec.get("lanes", 1),
                    "source": tpath}
-    peak = PEAK_BF16_DENSE_TFLOPS / 6 if x3 else PEAK_FP32_MATRIX_TFLOPS
-    kernel_desc = ("tail_x3_kernel + gemm_x3_kernel (fp32 operands split into 3 bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per "
-                   "product, fp32 accumulate; peak = bf16 dense 2500 TFLOP/s / 6; achieved = fp32-equivalent algorithmic GEMM "
-                   "flops of SURVEY.md 8d over the time a GEMM-class launch was running; the attention-apply products and the "
-                   "fused K^T V epilogue's own MFMAs are not counted)") if x3 else \
+    peak = PEAK_16BIT_DENSE_TFLOPS / n_prod if split_backend else PEAK_FP32_MATRIX_TFLOPS
+    kernel_desc = (("tail_kernel<%s> + gemm_split_kernel<%s> (fp32 operands split into %s, %d x v_mfma_f32_32x32x16_%s per "
+                    "product, fp32 accumulate; peak = 16-bit dense 2500 TFLOP/s / %d; achieved = fp32-equivalent algorithmic GEMM "
+                    "flops of SURVEY.md 8d over the time a GEMM-class launch was running; the attention-apply products and the "
+                    "fused K^T V epilogue's own MFMAs are not counted)")
+                   % (("SplitH2", "SplitH2", "2 fp16 planes with weight-derived power-of-two scales", 3, "f16", 3) if gb == "h2" else
+                      ("SplitBf3", "SplitBf3", "3 bf16 planes", 6, "bf16", 6))) if split_backend else \
                   ("gemm_f32_kernel (v_mfma_f32_32x32x2_f32; all epilogue instantiations; the fused K^T V epilogue's own "
                    "MFMAs are not counted as algorithmic flops)")
     if rank == 0:
@@ -483,6 +511,8 @@ def main():
             "metric": "registration pairs/sec", "value": round(total_pairs / elapsed, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "sustained_value": None if sustained is None else sustained[0],
+            "sustained": None if sustained is None else {"steps": sustained[1], "seconds": sustained[2]},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": {"3dmatch": "BASELINE configs[1]: synthetic 3DMatch_test-like pairs, voxel 0.0625 m, ~5k points/cloud",
                                     "kitti": "BASELINE configs[3]: synthetic KITTI_test-like pairs, voxel 0.7 m, ~13-16k points/cloud",
@@ -496,9 +526,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kernel_desc,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "mfma_tflops_issued": round(achieved * (6 if x3 else 1), 1),
+                         "mfma_tflops_issued": round(achieved * n_prod, 1),
                          "frac_of_fp32_matrix_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
-                         **({"frac_of_measured_mfma_rate_at_power_cap": round(achieved * 6 / MEASURED_BF16_MFMA_AT_POWER_CAP_TFLOPS, 4)} if x3 else {}),
+                         **({"frac_of_measured_mfma_rate_at_power_cap": round(achieved * n_prod / MEASURED_MFMA_AT_POWER_CAP_TFLOPS[gb], 4)} if split_backend else {}),
                          "launches": gemm_launches, "avg_ms": round(gemm_ms / gemm_launches, 4),
                          "busy_ms_per_step": round(gemm_busy_ms / args.steps, 3),
                          "summed_launch_ms_per_step": round(gemm_ms / args.steps, 3),

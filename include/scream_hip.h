@@ -13,7 +13,8 @@
  *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
  *   - returns 0 on success, a negative SCREAM_E* code on a rejected argument (checked on
  *     the host before any launch), or the positive hipError_t of a failed launch;
- *   - all floating point is IEEE fp32 (fp64 only inside the 3x3 Kabsch solve);
+ *   - every input, output and accumulation is IEEE fp32 (fp64 only inside the 3x3 Kabsch solve; the split GEMMs hold their
+ *     operands as exact sums of 16-bit planes inside the kernels, see scream_gemm_split_f32);
  *   - "rows" are points/tokens.  A *packed batch* holds several clouds back to back, each
  *     cloud starting on a 128-row boundary (SCREAM_ROW_TILE) and zero-padded to one, so a
  *     128-row tile never spans two clouds.
@@ -47,14 +48,14 @@ enum {
 };
 
 /* ---- Activation layouts of a [M, 256] fp32 matrix (M % 32 == 0).
- * Row-major is the default everywhere.  FRAGMENT-major (SCREAM_ACT_FRAG) is the layout the split-bf16 kernels pass
+ * Row-major is the default everywhere.  FRAGMENT-major (SCREAM_ACT_FRAG) is the layout the operand-split kernels pass
  * between each other inside scream_forward: element (row 32 t + r, feature 32 blk + 8 a + 4 h + b) -- t the 32-row group,
  * blk the 32-feature segment, a in 0..3, h in 0..1, b in 0..3 -- lives at float offset
  *     ((((t * 8 + blk) * 4 + a) * 64 + r + 32 h) * 4 + b.
  * A 32-row group occupies the same 32 KiB as in row-major, so slices of whole groups are the same pointers in both
  * layouts.  Why: lane r + 32 h of a wave owns exactly the 16-byte pieces 2a + h of every 128-byte segment of row r as an
  * MFMA operand; stored this way, each of its four loads per segment is one fully contiguous 1 KiB wave access instead of
- * 32 half-used cache lines (scream_amd/csrc/tail_x3.hip).  scream_act_layout converts a matrix between the two. */
+ * 32 half-used cache lines (scream_amd/csrc/tail_split.hip).  scream_act_layout converts a matrix between the two. */
 #define SCREAM_LAYOUT_A_FRAG 1 /* the GEMM's A operand is fragment-major */
 #define SCREAM_LAYOUT_C_FRAG 2 /* the activated (elu + 1) query tile of the GEMM's output is fragment-major */
 int scream_act_layout(const float* src, float* dst, int64_t M, int32_t to_fragment, void* stream);
@@ -88,90 +89,74 @@ int scream_gemm_qkv_f32(const float* A, int64_t lda, const float* W, float* Q, i
 int scream_kv_finalize(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
                        int64_t row_base, int32_t cloud_begin, int32_t n_kv, float* kv_out, void* stream);
 
-/* ---- The same two GEMM entry points on the bf16 matrix cores with 3-way operand splitting (fp32-level accuracy:
- * x = x0 + x1 + x2 in bf16, six bf16 MFMAs per 16-deep step, fp32 accumulate; scream_amd/csrc/gemm_x3.hip).
- * The weight matrix is pre-split and re-tiled ONCE by scream_pack_w_x3 (device to device): W [N,K] fp32 ->
- * W_packed, 6*N*K bytes: [3 planes][K/32 k-tiles][N][32] bf16 with plane p0 = bf16(W), p1 = bf16(W - p0),
- * p2 = bf16(W - p0 - p1), stored k-tile by k-tile in the order the kernel stages it in LDS.  A, C, residual and
- * bias stay fp32.  M % 128 == 0, N % 256 == 0, K = 64 + 192 j (64, 256, 448, ..., 1024: the k-loop rotates three
- * operand register sets over two LDS stages, so the k-tile count K/32 is even and 2 mod 3; anything else is
- * SCREAM_EUNSUPPORTED).  A row-block [n0, n0 + n) of W must be packed on its
- * own to be used as a GEMM operand on its own. */
-int scream_pack_w_x3(const float* W, int32_t N, int32_t K, void* W_packed, void* stream);
-int scream_gemm_x3_f32(const float* A, int64_t lda, const void* W_packed, float* C, int64_t ldc, int64_t M,
-                       int32_t N, int32_t K, int32_t epilogue, int32_t n_act, const float* bias,
-                       const float* residual, int64_t ldr, const float* gamma, const float* beta,
-                       void* stream);
-int scream_gemm_qkv_x3_f32(const float* A, int64_t lda, const void* W_packed, float* Q, int64_t ldq,
-                           int64_t M, int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
-                           const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
-                           float* kv_partial, void* stream);
-/* The same two with an explicit activation layout (SCREAM_LAYOUT_* bits): A fragment-major needs lda == K == 256;
- * C fragment-major applies to the activated tile of an ELU1 / QKV epilogue with n_act == ldc == 256 (the queries). */
-int scream_gemm_x3_ex_f32(const float* A, int64_t lda, const void* W_packed, float* C, int64_t ldc, int64_t M,
+/* ---- The same two GEMM entry points on the 16-bit matrix cores by OPERAND SPLITTING, fp32-level accuracy
+ * (scream_amd/csrc/gemm_split.hip, split.h).  `split` selects the arithmetic:
+ *   SCREAM_SPLIT_H2  (2): x 2^e = x0 + x1 in fp16, three fp16 MFMAs per 16-deep step (a1b0 + a0b1 + a0b0), fp32 accumulate --
+ *                    the default of the forward since round 3.  fp16 has a 5-bit exponent, so each operand carries an exact
+ *                    power-of-two scale: w_exp is baked into the packed weights, a_exp is applied to A as it is split, the
+ *                    accumulators are multiplied by 2^-(a_exp + w_exp).  CONTRACT: |A| 2^a_exp <= 2^15 and |W| 2^w_exp <= 2^15 for
+ *                    every element (fp16 overflows at 65 504; values below 2^-3 / 2^exp lose relative precision, so choose the
+ *                    largest exponent the bound allows).  scream_amd/scales.py derives a_exp for every GEMM of the forward from
+ *                    the weights alone (LayerNorm outputs are bounded by gamma / beta).
+ *   SCREAM_SPLIT_BF3 (3): x = x0 + x1 + x2 in bf16 (exact), six bf16 MFMAs per step; bf16 keeps fp32's exponent range, so
+ *                    a_exp / w_exp are ignored and the result is scale invariant bit for bit.  Rounds 1-2's arithmetic.
+ * The weight matrix is pre-split and re-tiled ONCE by scream_pack_w_split (device to device): W [N,K] fp32 ->
+ * W_packed, 2*split*N*K bytes: [split planes][K/32 k-tiles][N][32] 16-bit values, stored k-tile by k-tile in the order the
+ * kernel stages it in LDS.  A, C, residual and bias stay fp32.  M % 128 == 0, N % 256 == 0, K = 64 + 192 j (64, 256, 448, ...,
+ * 1024: the k-loop rotates three operand register sets over two LDS stages, so the k-tile count K/32 is even and 2 mod 3;
+ * anything else is SCREAM_EUNSUPPORTED).  A row-block [n0, n0 + n) of W must be packed on its own to be used as a GEMM
+ * operand on its own.  layout (SCREAM_LAYOUT_* bits): A fragment-major needs lda == K == 256; C fragment-major applies to the
+ * activated tile of an ELU1 / QKV epilogue with n_act == ldc == 256 (the queries). */
+#define SCREAM_SPLIT_H2 2
+#define SCREAM_SPLIT_BF3 3
+int scream_pack_w_split(const float* W, int32_t N, int32_t K, int32_t split, int32_t w_exp, void* W_packed,
+                        void* stream);
+int scream_gemm_split_f32(const float* A, int64_t lda, const void* W_packed, float* C, int64_t ldc, int64_t M,
                           int32_t N, int32_t K, int32_t epilogue, int32_t n_act, const float* bias,
                           const float* residual, int64_t ldr, const float* gamma, const float* beta,
-                          int32_t layout, void* stream);
-int scream_gemm_qkv_x3_ex_f32(const float* A, int64_t lda, const void* W_packed, float* Q, int64_t ldq,
+                          int32_t layout, int32_t split, int32_t a_exp, int32_t w_exp, void* stream);
+int scream_gemm_qkv_split_f32(const float* A, int64_t lda, const void* W_packed, float* Q, int64_t ldq,
                               int64_t M, int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
                               const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
-                              float* kv_partial, int32_t layout, void* stream);
-
-/* ---- A4 (FFN half) as ONE launch: y = LayerNorm(residual + W2 . relu(W1 . m1)), the 1024-wide hidden activations
- * never leave the register file (scream_amd/csrc/tail_x3.hip: transposed formulation, weights as the MFMA A operand).
- * Replaces models/transformer.py:66-72,86-88 (mlp = Linear(256,1024,no bias), ReLU, Linear(1024,256,no bias); norm2 of
- * x + mlp(.)), i.e. scream_gemm_x3_f32(EPI_RELU) followed by scream_gemm_x3_f32(EPI_RES_LN), with the same split-bf16
- * arithmetic.  scream_pack_ffn_x3 builds the 3 MiB weight image (scream_ffn_image_bytes()) once from W1 [1024,256] and
- * W2 [256,1024] fp32 (device to device).  m1, residual, y: [M, 256] fp32 with row strides ld* (multiples of 4),
- * M % 128 == 0; gamma/beta [256]. */
-int64_t scream_ffn_image_bytes(void);
-int scream_pack_ffn_x3(const float* W1, const float* W2, void* ffn_image, void* stream);
-int scream_ffn_x3_f32(const float* m1, int64_t ldm, const void* ffn_image, const float* residual, int64_t ldr,
-                      const float* gamma, const float* beta, float* y, int64_t ldy, int64_t M, void* stream);
+                              float* kv_partial, int32_t layout, int32_t split, int32_t a_exp, int32_t w_exp,
+                              void* stream);
 
 /* ---- A3 (apply) + A4 as ONE launch: everything of an MHAttention block that is local to a row,
  *     att = ((Q' . KV) * Z) * S;  m1 = LayerNorm1(att . Wm^T + x);  y = LayerNorm2(x + W2 . relu(W1 . m1))
- * Replaces models/transformer.py:41-42,83-88, i.e. scream_attn_apply + scream_gemm_x3_f32(merge, EPI_RES_LN) +
- * scream_ffn_x3_f32, with the same split-bf16 arithmetic; att, m1 and the hidden activations never reach memory
- * (scream_amd/csrc/tail_x3.hip).  Operands:
+ * Replaces models/transformer.py:41-42,83-88, i.e. scream_attn_apply + scream_gemm_split_f32(merge, EPI_RES_LN) +
+ * scream_gemm_split_f32(mlp.0, EPI_RELU) + scream_gemm_split_f32(mlp.2, EPI_RES_LN), with the same split arithmetic; att, m1
+ * and the 1024-wide hidden activations never reach memory (scream_amd/csrc/tail_split.hip).  Operands:
  * Q, x and y are FRAGMENT-major [M, 256] matrices (SCREAM_ACT_FRAG above; scream_act_layout converts):
- *   Q             the elu+1 mapped queries written by scream_gemm_qkv_x3_ex_f32 / scream_gemm_x3_ex_f32(EPI_ELU1) with
+ *   Q             the elu+1 mapped queries written by scream_gemm_qkv_split_f32 / scream_gemm_split_f32(EPI_ELU1) with
  *                 SCREAM_LAYOUT_C_FRAG;
  *   kv_image      scream_kv_image_bytes() per cloud, written by scream_kv_finalize_x3 from the K^T V partials of
- *                 scream_gemm_qkv_x3_f32 (same arguments as scream_kv_finalize): KV^T / S as MFMA operand fragments in
- *                 three bf16 planes + Ksum in fp32;  the key cloud of 128-row tile t is tile_cloud[t] + kv_cloud_offset
- *                 (tile_cloud points at the entry of the first row), cloud_len gives S;
+ *                 scream_gemm_qkv_split_f32 (same arguments as scream_kv_finalize): KV^T / S as MFMA operand fragments in
+ *                 three bf16 planes + Ksum in fp32 (the apply runs on the bf16 x 3 split for either `split`: 3 % of the
+ *                 kernel's matrix work, and KV is a data-dependent sum with no useful static bound);  the key cloud of 128-row
+ *                 tile t is tile_cloud[t] + kv_cloud_offset (tile_cloud points at the entry of the first row), cloud_len gives S;
  *   x             the block input (residual of BOTH norms), must not alias y;
- *   tail_image    scream_tail_image_bytes(), built once by scream_pack_tail_x3 from merge [256,256], mlp.0 [1024,256]
- *                 and mlp.2 [256,1024] (fp32, device to device).
+ *   tail_image    scream_tail_image_bytes(split), built once by scream_pack_tail from merge [256,256], mlp.0 [1024,256]
+ *                 and mlp.2 [256,1024] (fp32, device to device) for the same `split` and exponents;
+ *   exps          SCREAM_SPLIT_H2 only (NULL otherwise): the power-of-two exponents of the operands.  CONTRACT, for every value
+ *                 the operand can take: |att| 2^e_att, |m1| 2^e_m1, |relu(W1 m1)| 2^e_h <= 2^15 and |Wm| 2^e_wm, |W1| 2^e_w1,
+ *                 |W2| 2^e_w2 <= 2^15.  |att| <= max |v| (a convex combination of value rows), |m1| <= 16 |gamma1| + |beta1|,
+ *                 |W1 m1| <= 16 |W1_row * gamma1|_2 + |W1_row . beta1|: scream_amd/scales.py computes them from the weights.
+ *                 Exponents in [-40, 40], e_wm + e_att and e_w2 + e_h in [-44, 44] (SCREAM_EINVAL otherwise).
  * M % 128 == 0, every pointer 16-byte aligned. */
-int64_t scream_tail_image_bytes(void);
+typedef struct {
+    int32_t e_att, e_wm, e_m1, e_w1, e_h, e_w2;
+} scream_tail_exps_t;
+int64_t scream_tail_image_bytes(int32_t split);
 int64_t scream_kv_image_bytes(void);
-int scream_pack_tail_x3(const float* Wm, const float* W1, const float* W2, void* tail_image, void* stream);
+int scream_pack_tail(const float* Wm, const float* W1, const float* W2, int32_t split, const scream_tail_exps_t* exps,
+                     void* tail_image, void* stream);
 int scream_kv_finalize_x3(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
                           int64_t row_base, int32_t cloud_begin, int32_t n_kv, void* kv_image, void* stream);
-int scream_layer_tail_x3_f32(const float* Q, const void* kv_image, const int32_t* tile_cloud,
-                             int32_t kv_cloud_offset, const int32_t* cloud_len, const float* x,
-                             const void* tail_image, const float* g1, const float* b1, const float* g2,
-                             const float* b2, float* y, int64_t M, void* stream);
-
-/* ---- A2 + the reduce half of A3 in the geometry of the layer tail: the q / k / v projections of a block
- * (models/transformer.py:27-36: q_proj, k_proj, v_proj, elu + 1 on q and k) with the fused K^T V reduction (:38-41).
- * Same results as scream_gemm_qkv_x3_ex_f32 to rounding, fewer joules per row (scream_amd/csrc/proj_x3.hip): the bf16
- * planes of the input rows are made once per 128-row tile for all 24 output chunks, Q' leaves the accumulators in the
- * fragment-major layout without an LDS round trip, K'^T V is reduced by bf16 MFMAs straight from the split accumulators.
- *   proj_image: scream_pack_proj_x3(Wq, Wk, Wv) -- q_proj / k_proj / v_proj .weight, [256,256] fp32 each, device to device;
- *               8 query stages then 16 key/value stages of 48 KiB (scream_proj_image_bytes(1, 1) bytes).  Wq == NULL or
- *               Wk == Wv == NULL packs only the other part.  A full image serves all three modes: has_q only reads its
- *               first 8 stages, has_kv only takes the pointer image + scream_proj_image_bytes(1, 0).
- *   x [M,256] FRAGMENT-major fp32, M % 128 == 0;  has_q: Q [M,256] FRAGMENT-major = elu(x Wq^T) + 1;
- *   has_kv: kv_partial [M/128][8][33*32] as scream_gemm_qkv_f32 writes it (tile_cloud / cloud_row0 / cloud_len / row_base
- *   with the same meaning: row 0 of x is packed row row_base; padding rows are excluded from the sums). */
-int64_t scream_proj_image_bytes(int32_t has_q, int32_t has_kv);
-int scream_pack_proj_x3(const float* Wq, const float* Wk, const float* Wv, void* proj_image, void* stream);
-int scream_proj_x3_f32(const float* x, const void* proj_image, int32_t has_q, int32_t has_kv, float* Q,
-                       float* kv_partial, const int32_t* tile_cloud, const int32_t* cloud_row0,
-                       const int32_t* cloud_len, int64_t row_base, int64_t M, void* stream);
+int scream_layer_tail_f32(const float* Q, const void* kv_image, const int32_t* tile_cloud,
+                          int32_t kv_cloud_offset, const int32_t* cloud_len, const float* x,
+                          const void* tail_image, const float* g1, const float* b1, const float* g2,
+                          const float* b2, float* y, int64_t M, int32_t split, const scream_tail_exps_t* exps,
+                          void* stream);
 
 /* ---- A1: feats = LayerNorm(PE_sine(xyz) + W_e (xyz - center[cloud]) + b_e)
  * Replaces models/pointnet.py:45-48 (+ models/transformer.py:157-179).  xyz [rows,3] packed;
@@ -207,8 +192,8 @@ int scream_coor_head(const float* X, const float* W, const float* b, float* out,
 /* ---- Whole forward pass of PointTransformer over a packed batch (A1-A6).
  * Replaces models/pointnet.py:38-60 for B pairs at once (the reference asserts B == 1, :39-40). */
 typedef struct {
-    /* Weight matrices are fp32 [N,K] when scream_model_t.gemm_planes == 0 and scream_pack_w_x3 images of them
-     * (the pointers are then really const void*) when it is 1. */
+    /* Weight matrices are fp32 [N,K] when scream_model_t.gemm_split == 0 and scream_pack_w_split images of them
+     * (the pointers are then really const void*) when it is SCREAM_SPLIT_H2 / SCREAM_SPLIT_BF3. */
     const float* wqkv; /* [768,256]: q_proj | k_proj[0:128] | v_proj[0:128] | k_proj[128:256] | v_proj[128:256] */
     const float* wq;   /* rows [0,256) of wqkv as their own matrix (cross layers project q and k/v from different clouds) */
     const float* wkv;  /* rows [256,768) of wqkv as their own matrix */
@@ -217,16 +202,15 @@ typedef struct {
     const float* w2;   /* mlp.2 [256,1024] */
     const float* g1; const float* b1; /* norm1 */
     const float* g2; const float* b2; /* norm2 */
-    /* gemm_planes == 1 only; may be NULL.  scream_pack_ffn_x3 image of (w1, w2): the forward then runs the FFN half of the
-     * block as ONE launch (scream_ffn_x3_f32) instead of FFN-up + FFN-down, and ignores w1 / w2. */
-    const void* ffn;
-    /* gemm_planes == 1 only; may be NULL.  scream_pack_tail_x3 image of (wm, w1, w2): the forward then runs attention
-     * apply, merge + norm1 and the FFN + norm2 as ONE launch per block (scream_layer_tail_x3_f32) and ignores wm, w1, w2
-     * and ffn. */
+    /* gemm_split != 0 only; may be NULL.  scream_pack_tail image of (wm, w1, w2) for the same split: the forward then runs
+     * attention apply, merge + norm1 and the FFN + norm2 as ONE launch per block (scream_layer_tail_f32) and ignores wm, w1, w2. */
     const void* tail;
-    /* tail != NULL only; may be NULL.  scream_pack_proj_x3 image of (q_proj, k_proj, v_proj): the forward then runs the
-     * projections on scream_proj_x3_f32 and ignores wqkv / wq / wkv. */
-    const void* proj;
+    /* SCREAM_SPLIT_H2 only: power-of-two exponents (scream_amd/scales.py).  e_xq / e_xkv: the block input on the query side
+     * and on the key/value side (different clouds in a cross layer), bounded by the LayerNorm that produced it; e_wqkv, e_wq,
+     * e_wkv, e_wm_g, e_w1_g, e_w2_g: of the packed matrices above (the *_g ones only when wm / w1 / w2 run as separate GEMMs,
+     * with e_att / e_m1 / e_h of tail_exps as their input exponents); tail_exps: of the fused tail and its image. */
+    int32_t e_xq, e_xkv, e_wqkv, e_wq, e_wkv, e_wm_g, e_w1_g, e_w2_g;
+    scream_tail_exps_t tail_exps;
 } scream_layer_t;
 
 typedef struct {
@@ -243,10 +227,12 @@ typedef struct {
      * (models/pointnet.py:113-118,143-145): HOST array of n_self layers applied to the SECOND clouds (stem_dem) while
      * layers_host[0..n_self) (stem_dsm) are applied to the first clouds only. */
     const scream_layer_t* stem_tgt_layers_host;
-    /* 0: fp32 weights, fp32-input MFMA GEMMs (scream_gemm_f32).  1: every weight MATRIX above (wqkv/wq/wkv/wm/w1/w2,
-     * c0_w, c2_w) is a scream_pack_w_x3 image and the GEMMs run on scream_gemm_x3_f32 -- same fp32 results to
-     * rounding (tests/test_gpu_parity.py holds both to the same tolerances). */
-    int32_t gemm_planes;
+    /* 0: fp32 weights, fp32-input MFMA GEMMs (scream_gemm_f32).  SCREAM_SPLIT_H2 / SCREAM_SPLIT_BF3: every weight MATRIX
+     * above (wqkv/wq/wkv/wm/w1/w2, c0_w, c2_w) is a scream_pack_w_split image and the GEMMs run on scream_gemm_split_f32 --
+     * same fp32 results to rounding (tests/test_gpu_parity.py holds all three to the same tolerances). */
+    int32_t gemm_split;
+    /* SCREAM_SPLIT_H2 only: exponents of the coordinate MLP's two GEMMs (input: the last LayerNorm2 / relu(c0 . + b0)) */
+    int32_t e_c0x, e_c0w, e_c2x, e_c2w;
 } scream_model_t;
 
 typedef struct {
@@ -261,9 +247,11 @@ typedef struct {
     const int32_t* cloud_len;  /* [2B] */
 } scream_batch_t;
 
-/* Bytes of scratch scream_forward needs for this batch geometry. */
+/* Bytes of scratch scream_forward needs for this batch geometry.  fused_tail != 0: every layer carries a tail image (the
+ * default of the split backends) -- 3 KB per row (two feature buffers and Q'); otherwise the attention output, LayerNorm1
+ * output and FFN hidden buffers of the unfused chain are carved as well (9 KB per row). */
 int64_t scream_forward_workspace_bytes(int64_t rows_src, int64_t rows_total, int32_t n_pairs,
-                                       int32_t max_chunks);
+                                       int32_t max_chunks, int32_t fused_tail);
 
 /* src_pred [rows_src,3] (padding rows hold don't-care values).  If feats_out != NULL the final
  * source features [rows_src,256] are copied there (test hook).  trace: NULL, or a handle from

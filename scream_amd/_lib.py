@@ -12,7 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscream_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -20,8 +20,17 @@ c_u8p = C.POINTER(C.c_uint8)
 c_u64p = C.POINTER(C.c_uint64)
 
 
+SPLIT_H2, SPLIT_BF3 = 2, 3
+
+
+class TailExpsT(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("e_att", "e_wm", "e_m1", "e_w1", "e_h", "e_w2")]
+
+
 class LayerT(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "wq", "wkv", "wm", "w1", "w2", "g1", "b1", "g2", "b2", "ffn", "tail", "proj")]
+    _fields_ = ([(n, C.c_void_p) for n in ("wqkv", "wq", "wkv", "wm", "w1", "w2", "g1", "b1", "g2", "b2", "tail")] +
+                [(n, C.c_int32) for n in ("e_xq", "e_xkv", "e_wqkv", "e_wq", "e_wkv", "e_wm_g", "e_w1_g", "e_w2_g")] +
+                [("tail_exps", TailExpsT)])
 
 
 class ModelT(C.Structure):
@@ -29,7 +38,8 @@ class ModelT(C.Structure):
                 ("emb_b", C.c_void_p), ("pre_g", C.c_void_p), ("pre_b", C.c_void_p),
                 ("layers_host", C.POINTER(LayerT)), ("c0_w", C.c_void_p), ("c0_b", C.c_void_p),
                 ("c2_w", C.c_void_p), ("c2_b", C.c_void_p), ("c4_w", C.c_void_p), ("c4_b", C.c_void_p),
-                ("stem_tgt_layers_host", C.POINTER(LayerT)), ("gemm_planes", C.c_int32)]
+                ("stem_tgt_layers_host", C.POINTER(LayerT)), ("gemm_split", C.c_int32),
+                ("e_c0x", C.c_int32), ("e_c0w", C.c_int32), ("e_c2x", C.c_int32), ("e_c2w", C.c_int32)]
 
 
 class BatchT(C.Structure):
@@ -46,28 +56,20 @@ SIGNATURES = {
     "scream_gemm_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, I32, V, V, I64, V, V, V]),
     "scream_gemm_qkv_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, V, V, V, I64, V, V]),
     "scream_kv_finalize": (C.c_int, [V, V, V, I64, I32, I32, V, V]),
-    "scream_pack_w_x3": (C.c_int, [V, I32, I32, V, V]),
-    "scream_gemm_x3_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, I32, V, V, I64, V, V, V]),
-    "scream_gemm_qkv_x3_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, V, V, V, I64, V, V]),
-    "scream_ffn_image_bytes": (C.c_int64, []),
-    "scream_pack_ffn_x3": (C.c_int, [V, V, V, V]),
-    "scream_ffn_x3_f32": (C.c_int, [V, I64, V, V, I64, V, V, V, I64, I64, V]),
-    "scream_tail_image_bytes": (C.c_int64, []),
+    "scream_pack_w_split": (C.c_int, [V, I32, I32, I32, I32, V, V]),
+    "scream_gemm_split_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, I32, V, V, I64, V, V, I32, I32, I32, I32, V]),
+    "scream_gemm_qkv_split_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, V, V, V, I64, V, I32, I32, I32, I32, V]),
+    "scream_tail_image_bytes": (C.c_int64, [I32]),
     "scream_kv_image_bytes": (C.c_int64, []),
-    "scream_pack_tail_x3": (C.c_int, [V, V, V, V, V]),
+    "scream_pack_tail": (C.c_int, [V, V, V, I32, C.POINTER(TailExpsT), V, V]),
     "scream_kv_finalize_x3": (C.c_int, [V, V, V, I64, I32, I32, V, V]),
-    "scream_layer_tail_x3_f32": (C.c_int, [V, V, V, I32, V, V, V, V, V, V, V, V, I64, V]),
+    "scream_layer_tail_f32": (C.c_int, [V, V, V, I32, V, V, V, V, V, V, V, V, I64, I32, C.POINTER(TailExpsT), V]),
     "scream_act_layout": (C.c_int, [V, V, I64, I32, V]),
-    "scream_proj_image_bytes": (I64, [I32, I32]),
-    "scream_pack_proj_x3": (C.c_int, [V, V, V, V, V]),
-    "scream_proj_x3_f32": (C.c_int, [V, V, I32, I32, V, V, V, V, V, I64, I64, V]),
-    "scream_gemm_x3_ex_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, I32, V, V, I64, V, V, I32, V]),
-    "scream_gemm_qkv_x3_ex_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, V, V, V, I64, V, I32, V]),
     "scream_pe_embed_ln": (C.c_int, [V, V, V, V, V, V, V, V, V, I64, V]),
     "scream_kv_reduce": (C.c_int, [V, V, I64, I64, V, V, I32, I32, I32, V, V, V]),
     "scream_attn_apply": (C.c_int, [V, I64, V, V, I32, V, V, I64, I64, V]),
     "scream_coor_head": (C.c_int, [V, V, V, V, I64, V]),
-    "scream_forward_workspace_bytes": (C.c_int64, [I64, I64, I32, I32]),
+    "scream_forward_workspace_bytes": (C.c_int64, [I64, I64, I32, I32, I32]),
     "scream_forward": (C.c_int, [C.POINTER(ModelT), C.POINTER(BatchT), V, I64, V, V, V, V]),
     "scream_trace_create": (C.c_void_p, [I32]),
     "scream_trace_destroy": (None, [V]),

@@ -16,11 +16,10 @@ ARCH = "gfx950"
 # parity-critical files keep every fp32 operation individually rounded (see the file headers)
 SOURCES = {
     "gemm_f32.hip": [],
-    "gemm_x3.hip": [],
+    "gemm_split.hip": [],
     # several code instances of the same arithmetic (an attention apply in the open / riding under another stage) must round
     # identically, whatever hipcc makes of each: no fma contraction in this file
-    "tail_x3.hip": ["-ffp-contract=off"],
-    "proj_x3.hip": ["-ffp-contract=off"],
+    "tail_split.hip": ["-ffp-contract=off"],
     "embed.hip": [],
     "attention.hip": [],
     "forward.hip": [],
@@ -28,9 +27,8 @@ SOURCES = {
     "kabsch.hip": ["-ffp-contract=off"],
     "icp_grid.hip": ["-ffp-contract=off"],
 }
-# SCREAM_TAIL_MFMA16=1 builds the layer tail on v_mfma_f32_16x16x32_bf16 (tail_x3.hip: same results, same joules, +0.8 %)
-EXTRA_DEFINES = {"tail_x3.hip": ["-DT_MFMA16=%d" % int(os.environ.get("SCREAM_TAIL_MFMA16", "0") != "0")]}
-ASM_LOADS = ("gemm_x3.hip", "tail_x3.hip", "proj_x3.hip")  # verified after code generation, see verify_one
+EXTRA_DEFINES = {}
+ASM_LOADS = ("gemm_split.hip", "tail_split.hip")  # verified after code generation, see verify_one
 
 
 def _hipcc() -> str:

@@ -21,7 +21,10 @@ struct Workspace {
     int64_t bytes;
 };
 
-Workspace carve(void* base, int64_t rows_total, int32_t n_pairs, int32_t max_chunks) {
+// fused: every layer runs its tail as one launch -- the attention output, LayerNorm1 output and FFN hidden buffers of the
+// unfused chain (6 KB per row) are then not carved (3 KB per row remain: two feature buffers and Q'); the coordinate MLP's
+// two intermediates go into Q' and the idle feature buffer.
+Workspace carve(void* base, int64_t rows_total, int32_t n_pairs, int32_t max_chunks, bool fused) {
     Workspace w;
     float* p = reinterpret_cast<float*>(base);
     auto take = [&](int64_t n) {
@@ -32,9 +35,9 @@ Workspace carve(void* base, int64_t rows_total, int32_t n_pairs, int32_t max_chu
     w.x0 = take(rows_total * D);
     w.x1 = take(rows_total * D);
     w.q = take(rows_total * D);
-    w.att = take(rows_total * D);
-    w.m1 = take(rows_total * D);
-    w.hid = take(rows_total * 4 * D);
+    w.att = fused ? nullptr : take(rows_total * D);
+    w.m1 = fused ? nullptr : take(rows_total * D);
+    w.hid = fused ? nullptr : take(rows_total * 4 * D);
     w.kvp = take(rows_total / SCREAM_ROW_TILE * SCREAM_NHEAD * KV_ELEMS);  // one K^T V partial per 128-row tile and head
     w.kv = take((int64_t)2 * n_pairs * SCREAM_NHEAD * KV_ELEMS);
     w.kvimg = reinterpret_cast<char*>(take((int64_t)2 * n_pairs * scream_kv_image_bytes() / 4));
@@ -76,31 +79,32 @@ struct Scope {  // records start on construction, stop on destruction
         if (rc_ != 0) return rc_; \
     } while (0)
 
-enum { TR_FFN_FUSED = 6, TR_TAIL_FUSED = 7, TR_EMBED = 100, TR_KV_REDUCE = 101, TR_ATTN_APPLY = 102, TR_COOR_HEAD = 103 };
+enum { TR_TAIL_FUSED = 7, TR_EMBED = 100, TR_KV_REDUCE = 101, TR_ATTN_APPLY = 102, TR_COOR_HEAD = 103 };
 
 struct Ctx {
     void* st;
     Trace* tr;
-    bool planes;  // scream_model_t.gemm_planes: weights are bf16 plane blocks, GEMMs on the split kernel
+    int split;    // scream_model_t.gemm_split: 0 = fp32 weights, else the weights are packed operand planes, GEMMs on the split kernel
     bool frag;    // every layer has a fused-tail image: the features travel FRAGMENT-major between the kernels (SCREAM_ACT_FRAG)
 };
 
+// a_exp / w_exp: SCREAM_SPLIT_H2's operand exponents (ignored otherwise)
 int gemm(const Ctx& c, const float* A, int64_t lda, const float* W, float* C, int64_t ldc, int64_t M, int N, int K,
-         int epi, int n_act, const float* bias, const float* res, const float* g, const float* b, int layout = 0) {
+         int epi, int n_act, const float* bias, const float* res, const float* g, const float* b, int a_exp, int w_exp,
+         int layout = 0) {
     Scope sc(c.tr, epi, M, N, K, c.st);
-    if (c.planes) return scream_gemm_x3_ex_f32(A, lda, W, C, ldc, M, N, K, epi, n_act, bias, res, D, g, b, layout, c.st);
+    if (c.split)
+        return scream_gemm_split_f32(A, lda, W, C, ldc, M, N, K, epi, n_act, bias, res, D, g, b, layout, c.split, a_exp, w_exp, c.st);
     return scream_gemm_f32(A, lda, W, C, ldc, M, N, K, epi, n_act, bias, res, D, g, b, c.st);
 }
 
-int gemm_qkv(const Ctx& c, const float* A, const float* W, const void* proj, float* Q, int64_t M, int N, int n_q,
-             const scream_batch_t& b, int64_t row_base, float* kvp) {
+int gemm_qkv(const Ctx& c, const float* A, const float* W, float* Q, int64_t M, int N, int n_q, const scream_batch_t& b,
+             int64_t row_base, float* kvp, int a_exp, int w_exp) {
     Scope sc(c.tr, 5, M, N, D, c.st);
-    if (c.frag && proj)  // ring-design projection kernel (proj_x3.hip); the image holds 8 query stages, then 16 key/value stages
-        return scream_proj_x3_f32(A, n_q ? proj : static_cast<const char*>(proj) + scream_proj_image_bytes(1, 0), n_q != 0, 1, Q, kvp,
-                                  b.tile_cloud, b.cloud_row0, b.cloud_len, row_base, M, c.st);
-    if (c.planes)
-        return scream_gemm_qkv_x3_ex_f32(A, D, W, Q, D, M, N, D, n_q, b.tile_cloud, b.cloud_row0, b.cloud_len, row_base, kvp,
-                                         c.frag ? (SCREAM_LAYOUT_A_FRAG | (n_q ? SCREAM_LAYOUT_C_FRAG : 0)) : 0, c.st);
+    if (c.split)
+        return scream_gemm_qkv_split_f32(A, D, W, Q, D, M, N, D, n_q, b.tile_cloud, b.cloud_row0, b.cloud_len, row_base, kvp,
+                                         c.frag ? (SCREAM_LAYOUT_A_FRAG | (n_q ? SCREAM_LAYOUT_C_FRAG : 0)) : 0, c.split, a_exp,
+                                         w_exp, c.st);
     return scream_gemm_qkv_f32(A, D, W, Q, D, M, N, D, n_q, b.tile_cloud, b.cloud_row0, b.cloud_len, row_base, kvp, c.st);
 }
 
@@ -111,13 +115,10 @@ int mha_tail(const Ctx& c, const scream_layer_t& L, const Workspace& w, const fl
     float* att = w.att + row0 * D;
     float* m1 = w.m1 + row0 * D;
     float* hid = w.hid + row0 * 4 * D;
-    TRY(gemm(c, att, D, L.wm, m1, D, rows, D, D, SCREAM_EPI_RES_LN, 0, nullptr, x, L.g1, L.b1));
-    if (c.planes && L.ffn) {  // FFN-up, relu, FFN-down, residual and LayerNorm2 in one launch: the hidden activations stay on chip
-        Scope sc(c.tr, TR_FFN_FUSED, rows, 4 * D, D, c.st);
-        return scream_ffn_x3_f32(m1, D, L.ffn, x, D, L.g2, L.b2, y, D, rows, c.st);
-    }
-    TRY(gemm(c, m1, D, L.w1, hid, 4 * D, rows, 4 * D, D, SCREAM_EPI_RELU, 0, nullptr, nullptr, nullptr, nullptr));
-    TRY(gemm(c, hid, 4 * D, L.w2, y, D, rows, D, 4 * D, SCREAM_EPI_RES_LN, 0, nullptr, x, L.g2, L.b2));
+    const scream_tail_exps_t& e = L.tail_exps;  // the operands of the three GEMMs are the fused tail's: att, m1, hidden
+    TRY(gemm(c, att, D, L.wm, m1, D, rows, D, D, SCREAM_EPI_RES_LN, 0, nullptr, x, L.g1, L.b1, e.e_att, L.e_wm_g));
+    TRY(gemm(c, m1, D, L.w1, hid, 4 * D, rows, 4 * D, D, SCREAM_EPI_RELU, 0, nullptr, nullptr, nullptr, nullptr, e.e_m1, L.e_w1_g));
+    TRY(gemm(c, hid, 4 * D, L.w2, y, D, rows, D, 4 * D, SCREAM_EPI_RES_LN, 0, nullptr, x, L.g2, L.b2, e.e_h, L.e_w2_g));
     return 0;
 }
 
@@ -129,15 +130,15 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
     const float* xr = x + row0 * D;
     float* qr = w.q + row0 * D;
     float* kvp = w.kvp + row0 / SCREAM_ROW_TILE * SCREAM_NHEAD * KV_ELEMS;
-    TRY(gemm_qkv(c, xr, L.wqkv, L.proj, qr, rows, 3 * D, D, b, row0, kvp));
+    TRY(gemm_qkv(c, xr, L.wqkv, qr, rows, 3 * D, D, b, row0, kvp, L.e_xq, L.e_wqkv));
     if (c.frag) {  // apply + merge + norm1 + FFN + norm2 in one launch
         {
             Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
             TRY(scream_kv_finalize_x3(kvp, b.cloud_row0, b.cloud_len, row0, cloud_begin, n_clouds, w.kvimg, c.st));
         }
         Scope sc(c.tr, TR_TAIL_FUSED, rows, 9 * D, D, c.st);  // merge (256) + FFN up and down (2 x 1024) output columns per row
-        return scream_layer_tail_x3_f32(qr, w.kvimg, b.tile_cloud + row0 / SCREAM_ROW_TILE, 0, b.cloud_len, xr, L.tail, L.g1,
-                                        L.b1, L.g2, L.b2, y + row0 * D, rows, c.st);
+        return scream_layer_tail_f32(qr, w.kvimg, b.tile_cloud + row0 / SCREAM_ROW_TILE, 0, b.cloud_len, xr, L.tail, L.g1,
+                                     L.b1, L.g2, L.b2, y + row0 * D, rows, c.split, &L.tail_exps, c.st);
     }
     {
         Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
@@ -155,22 +156,17 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
 int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x_src,
               const float* x_tgt, float* y) {
     const int64_t rs = b.rows_src, rt = b.rows_total - b.rows_src;
-    if (c.frag && L.proj) {
-        Scope sc(c.tr, SCREAM_EPI_ELU1, rs, D, D, c.st);
-        TRY(scream_proj_x3_f32(x_src, L.proj, 1, 0, w.q, nullptr, nullptr, nullptr, nullptr, 0, rs, c.st));
-    } else {
-        TRY(gemm(c, x_src, D, L.wq, w.q, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr,
-                 c.frag ? (SCREAM_LAYOUT_A_FRAG | SCREAM_LAYOUT_C_FRAG) : 0));
-    }
-    TRY(gemm_qkv(c, x_tgt, L.wkv, L.proj, nullptr, rt, 2 * D, 0, b, rs, w.kvp));
+    TRY(gemm(c, x_src, D, L.wq, w.q, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr, L.e_xq, L.e_wq,
+             c.frag ? (SCREAM_LAYOUT_A_FRAG | SCREAM_LAYOUT_C_FRAG) : 0));
+    TRY(gemm_qkv(c, x_tgt, L.wkv, nullptr, rt, 2 * D, 0, b, rs, w.kvp, L.e_xkv, L.e_wkv));
     if (c.frag) {
         {
             Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
             TRY(scream_kv_finalize_x3(w.kvp, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs, w.kvimg, c.st));
         }
         Scope sc(c.tr, TR_TAIL_FUSED, rs, 9 * D, D, c.st);
-        return scream_layer_tail_x3_f32(w.q, w.kvimg, b.tile_cloud, b.n_pairs, b.cloud_len, x_src, L.tail, L.g1, L.b1, L.g2, L.b2,
-                                        y, rs, c.st);
+        return scream_layer_tail_f32(w.q, w.kvimg, b.tile_cloud, b.n_pairs, b.cloud_len, x_src, L.tail, L.g1, L.b1, L.g2, L.b2,
+                                     y, rs, c.split, &L.tail_exps, c.st);
     }
     {
         Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
@@ -185,8 +181,8 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
 
 }  // namespace
 
-extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi10"; }
-extern "C" int scream_abi_version(void) { return 10; }
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi11"; }
+extern "C" int scream_abi_version(void) { return 11; }
 
 extern "C" void* scream_trace_create(int32_t capacity) {
     if (capacity <= 0) return nullptr;
@@ -244,9 +240,9 @@ extern "C" int scream_trace_read_starts(void* trace, int32_t max_records, float*
 }
 
 extern "C" int64_t scream_forward_workspace_bytes(int64_t rows_src, int64_t rows_total, int32_t n_pairs,
-                                                  int32_t max_chunks) {
+                                                  int32_t max_chunks, int32_t fused_tail) {
     if (rows_src < 0 || rows_total < rows_src || n_pairs < 0 || max_chunks < 0) return SCREAM_EINVAL;
-    return carve(nullptr, rows_total, n_pairs, max_chunks).bytes + 256;
+    return carve(nullptr, rows_total, n_pairs, max_chunks, fused_tail != 0).bytes + 256;
 }
 
 extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t* batch, void* workspace,
@@ -254,20 +250,21 @@ extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t*
     SCREAM_REQUIRE(model && batch && workspace && src_pred, SCREAM_EINVAL);
     const scream_model_t& m = *model;
     const scream_batch_t& b = *batch;
-    SCREAM_REQUIRE(m.layers_host && m.n_self >= 0 && m.n_cross >= 0 && (m.gemm_planes == 0 || m.gemm_planes == 1), SCREAM_EINVAL);
+    SCREAM_REQUIRE(m.layers_host && m.n_self >= 0 && m.n_cross >= 0 &&
+                       (m.gemm_split == 0 || m.gemm_split == SCREAM_SPLIT_H2 || m.gemm_split == SCREAM_SPLIT_BF3), SCREAM_EINVAL);
     SCREAM_REQUIRE(b.n_pairs > 0 && b.rows_src > 0 && b.rows_total > b.rows_src && b.max_chunks > 0, SCREAM_EINVAL);
     SCREAM_REQUIRE(b.rows_src % SCREAM_ROW_TILE == 0 && b.rows_total % SCREAM_ROW_TILE == 0, SCREAM_EUNSUPPORTED);
     SCREAM_REQUIRE(b.xyz && b.center && b.tile_cloud && b.cloud_row0 && b.cloud_len, SCREAM_EINVAL);
-    uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
-    const Workspace w = carve(reinterpret_cast<void*>(base), b.rows_total, b.n_pairs, b.max_chunks);
-    SCREAM_REQUIRE((int64_t)(base - reinterpret_cast<uintptr_t>(workspace)) + w.bytes <= workspace_bytes, SCREAM_EINVAL);
     // fragment-major features between the kernels iff EVERY layer carries a fused-tail image (all or none)
     int n_layers = m.n_self + 2 * m.n_cross, n_tail = 0;
     for (int i = 0; i < n_layers; ++i) n_tail += m.layers_host[i].tail != nullptr;
     if (m.stem_tgt_layers_host)
         for (int i = 0; i < m.n_self; ++i, ++n_layers) n_tail += m.stem_tgt_layers_host[i].tail != nullptr;
-    SCREAM_REQUIRE(n_tail == 0 || (n_tail == n_layers && m.gemm_planes == 1), SCREAM_EINVAL);
-    const Ctx c{stream, reinterpret_cast<Trace*>(trace), m.gemm_planes != 0, n_tail > 0};
+    SCREAM_REQUIRE(n_tail == 0 || (n_tail == n_layers && m.gemm_split != 0), SCREAM_EINVAL);
+    uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
+    const Workspace w = carve(reinterpret_cast<void*>(base), b.rows_total, b.n_pairs, b.max_chunks, n_tail > 0);
+    SCREAM_REQUIRE((int64_t)(base - reinterpret_cast<uintptr_t>(workspace)) + w.bytes <= workspace_bytes, SCREAM_EINVAL);
+    const Ctx c{stream, reinterpret_cast<Trace*>(trace), m.gemm_split, n_tail > 0};
 
     const int64_t rs = b.rows_src, ra = b.rows_total;
     {
@@ -302,12 +299,14 @@ extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t*
         nxt = t;
     }
     // coor_mlp, pointnet.py:27-33,60
-    TRY(gemm(c, cur, D, m.c0_w, w.m1, D, rs, D, D, SCREAM_EPI_BIAS_RELU, 0, m.c0_b, nullptr, nullptr, nullptr,
+    float* c_mid = c.frag ? w.q : w.m1;   // (fused: Q' and the idle feature buffer are dead by now)
+    float* c_out = c.frag ? nxt : w.att;
+    TRY(gemm(c, cur, D, m.c0_w, c_mid, D, rs, D, D, SCREAM_EPI_BIAS_RELU, 0, m.c0_b, nullptr, nullptr, nullptr, m.e_c0x, m.e_c0w,
              c.frag ? SCREAM_LAYOUT_A_FRAG : 0));  // the output (and everything behind it) is row-major
-    TRY(gemm(c, w.m1, D, m.c2_w, w.att, D, rs, D, D, SCREAM_EPI_BIAS_RELU, 0, m.c2_b, nullptr, nullptr, nullptr));
+    TRY(gemm(c, c_mid, D, m.c2_w, c_out, D, rs, D, D, SCREAM_EPI_BIAS_RELU, 0, m.c2_b, nullptr, nullptr, nullptr, m.e_c2x, m.e_c2w));
     {
         Scope sc(c.tr, TR_COOR_HEAD, rs, 0, 0, stream);
-        TRY(scream_coor_head(w.att, m.c4_w, m.c4_b, src_pred, rs, stream));
+        TRY(scream_coor_head(c_out, m.c4_w, m.c4_b, src_pred, rs, stream));
     }
     if (feats_out && c.frag) {
         TRY(scream_act_layout(cur, feats_out, rs, 0, stream));

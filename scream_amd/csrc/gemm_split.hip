@@ -1,19 +1,25 @@
-// fp32-accurate GEMM  C[M,N] = epilogue(A[M,K] . W[N,K]^T)  on the gfx950 bf16 matrix cores by 3-way operand splitting.
+// fp32-accurate GEMM  C[M,N] = epilogue(A[M,K] . W[N,K]^T)  on the gfx950 16-bit matrix cores by operand splitting
+// (split.h); the kernel is a template over the split:
 //
-//   x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)     (exact: 3 x 8 significand bits = fp32)
-//   a.b ~= a2b0 + a1b1 + a0b2 + a1b0 + a0b1 + a0b0                                  (dropped terms <= 2^-24 relative)
+//   SplitBf3:  x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)   (exact: 3 x 8 significand bits)
+//              a.b ~= a2b0 + a1b1 + a0b2 + a1b0 + a0b1 + a0b0                                (dropped terms <= 2^-24 relative)
+//   SplitH2:   x 2^e = x0 + x1,  x0 = fp16(x 2^e), x1 = fp16(x 2^e - x0)                    (2 x 11 significand bits)
+//              a.b ~= (a1b0 + a0b1 + a0b0) 2^-(ea + ew)                                      (half the matrix instructions)
 //
-// Every bf16 x bf16 product is exact in fp32 and the six v_mfma_f32_32x32x16_bf16 of a 16-deep step accumulate in
-// fp32, so the result carries fp32-level error -- measured against fp64 it is slightly MORE accurate than the
-// fp32-input MFMA path (max |err| / sum|a||b|: 2.0e-7 vs 2.6e-7 at K = 256, 2.8e-7 vs 3.4e-7 at K = 1024,
-// tools/x3_bench.py) -- while the matrix pipe spends 6 x 32 = 192 cycles per 32x32x16 block instead of 8 x 64 = 512.
-// Same inputs, same outputs, same epilogues and tolerances as gemm_f32.hip; the dtype of the path stays fp32.
+// Every 16-bit x 16-bit product is exact in fp32 and the MFMAs of a 16-deep step accumulate in fp32, so the result carries
+// fp32-level error -- measured against fp64 with the hardware's accumulation both are at or below the fp32-input MFMA path
+// (max |err| / sum|a||b| on rows of mixed scale: 2.6-3.7e-7 for SplitBf3, 1.9-2.1e-7 for SplitH2, tools/ubench/split_acc.py,
+// profiles/r03_split_acc.txt) -- while the matrix pipe spends 6 x 32 = 192 (3 x 32 = 96) cycles per 32x32x16 block instead of
+// 8 x 64 = 512.  Same inputs, same outputs, same epilogues and tolerances as gemm_f32.hip; the dtype of the path stays fp32.
+// SplitH2's power-of-two scales are arguments (a_exp, w_exp): the CALLER guarantees |A| 2^a_exp <= 2^15 (scream_amd/scales.py
+// derives it from the weights for every GEMM of the forward); the accumulators are multiplied by 2^-(a_exp + w_exp), exactly,
+// in front of the epilogue.
 //
 // Geometry: block tile 256 x 256, 512 threads = 8 waves stacked in M (wave tile 32 x 256, 128 accumulator VGPRs), one
 // persistent block per CU.
-//   * W is split and re-tiled once (scream_pack_w_x3) into an image that is stored k-tile by k-tile exactly as it sits
-//     in LDS: [3 planes][K/32][N][32] bf16, rows of 64 B whose 16-byte chunk c lives at c ^ ((n >> 2) & 3) so that the 16
-//     lanes of a ds_read_b128 group cover 16 distinct bank slots.  A k-tile stage is 48 one-KiB LDS-DMA pieces of
+//   * W is split and re-tiled once (scream_pack_w_split) into an image that is stored k-tile by k-tile exactly as it sits
+//     in LDS: [NP planes][K/32][N][32] 16-bit values, rows of 64 B whose 16-byte chunk c lives at c ^ ((n >> 2) & 3) so that the 16
+//     lanes of a ds_read_b128 group cover 16 distinct bank slots.  A k-tile stage is 16 NP one-KiB LDS-DMA pieces of
 //     CONTIGUOUS memory (with a plain [N][K] plane every piece touched 16 lines for half their bytes); double buffered.
 //   * A stays fp32 in HBM: lane (r, half) streams its 16 floats of row r per k-tile straight into registers (three
 //     register sets, requested TWO k-tiles ahead) and splits them there (v_cvt_pk_bf16_f32 + subtract, twice).
@@ -48,6 +54,7 @@
 #include <type_traits>
 
 #include "gemm_epilogue.h"
+#include "split.h"
 
 #ifdef X3_STAMPS  // tuning aid: s_memtime stamps of one output tile per block (tools/x3_stamps.py)
 __device__ long long x3_stamps[256 * 8 * 160];
@@ -65,28 +72,13 @@ extern "C" int scream_x3_stamps_read(long long* host) {
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int XBM = 256, XBN = 256, XBK = 32, XTHREADS = 512, XWAVES = 8;
-constexpr int PLANE_BYTES = XBN * XBK * 2;     // 16 KiB
-constexpr int STAGE_BYTES = 3 * PLANE_BYTES;   // 48 KiB
+constexpr int PLANE_BYTES = XBN * XBK * 2;     // 16 KiB; a k-tile stage is SP::NP of them
 constexpr int SLAB_BYTES = XWAVES * 8 * 256 * 4;  // 64 KiB
 constexpr int X_MAX_GRID = 256;
-
-__device__ __forceinline__ void split3(const f32x4 lo, const f32x4 hi, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float x = i < 4 ? lo[i] : hi[i - 4];
-        const __bf16 a = (__bf16)x;
-        const float r1 = x - (float)a;
-        const __bf16 b = (__bf16)r1;
-        p0[i] = a;
-        p1[i] = b;
-        p2[i] = (__bf16)(r1 - (float)b);
-    }
-}
 
 // s_waitcnt vmcnt(N) lgkmcnt(0) + workgroup barrier: the N youngest vector-memory operations of this wave (the A
 // loads of the k-tile after next) stay in flight across the barrier.
@@ -96,12 +88,16 @@ __device__ __forceinline__ void ring_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
-template <int EPI, bool AFRAG>
-__global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __restrict__ A, int64_t lda,
-                                                             const __bf16* __restrict__ Wp, float* __restrict__ C,
-                                                             int64_t ldc, int64_t M, int n_tiles, unsigned total_tiles,
-                                                             int N, int K, EpiArgs ep) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + SLAB_BYTES];  // 160 KiB
+template <class SP, int EPI, bool AFRAG>
+__global__ __launch_bounds__(XTHREADS, 2) void gemm_split_kernel(const float* __restrict__ A, int64_t lda,
+                                                                const char* __restrict__ Wp, float* __restrict__ C,
+                                                                int64_t ldc, int64_t M, int n_tiles, unsigned total_tiles,
+                                                                int N, int K, float a_scale, float c_scale, EpiArgs ep) {
+    typedef typename SP::vec V;
+    constexpr int NP = SP::NP;
+    constexpr int STAGE_BYTES = NP * PLANE_BYTES;  // 48 / 32 KiB
+    constexpr int WPW = 2 * NP;                    // LDS-DMA pieces per wave and k-tile
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + SLAB_BYTES];  // 160 / 128 KiB
     float* slabs = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,17 +108,17 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
         const unsigned xcd = v & 7u;
         return (xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8) + (v >> 3);
     };
-    // DMA: 48 one-KiB pieces per k-tile (3 planes x 16 pieces of 16 rows x 64 B), six per wave.  The packed weight
-    // image (scream_pack_w_x3) is stored k-tile by k-tile exactly as it sits in LDS, chunk swizzle included, so
+    // DMA: 16 NP one-KiB pieces per k-tile (NP planes x 16 pieces of 16 rows x 64 B), 2 NP per wave.  The packed weight
+    // image (scream_pack_w_split) is stored k-tile by k-tile exactly as it sits in LDS, chunk swizzle included, so
     // every piece is 1 KiB of CONTIGUOUS memory (eight full 128-byte lines, no over-fetch) and the per-lane part
     // of the address is just lane * 16 bytes.
-    const __bf16* w_lane = Wp + lane * 8;
+    const char* w_lane = Wp + lane * 16;
     auto dma_w = [&](int n0, int stage, int kt) {
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int id = wave * 6 + u, plane = id >> 4, q = id & 15;
-            const int64_t soff = (((int64_t)plane * (K / XBK) + kt) * N + n0 + q * 16) * XBK;  // scalar
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_lane + soff),
+        for (int u = 0; u < WPW; ++u) {
+            const int id = wave * WPW + u, plane = id >> 4, q = id & 15;
+            const int64_t soff = (((int64_t)plane * (K / XBK) + kt) * N + n0 + q * 16) * XBK;  // scalar, in 16-bit elements
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_lane + 2 * soff),
                                              (lptr_t)(smem + stage * STAGE_BYTES + plane * PLANE_BYTES + q * 1024), 16, 0, 0);
         }
     };
@@ -176,7 +172,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
     };
     request_first();
 
-    bf16x8 pa_s0[3];  // split planes of the first 16-deep step of the k-tile about to be computed
+    V pa_s0[NP];  // split planes of the first 16-deep step of the k-tile about to be computed
     const bool late = wave >= 4;  // the second wave of each SIMD
 #ifdef X3_STAMPS
     int tile_no = 0;
@@ -199,41 +195,37 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
         // loads in flight -- are issued between the two steps instead of in the post-barrier bubble.
         // tail: 0 steady, 1 = only D(kt+1) left to request, 2 = nothing.  Compile-time on purpose: with a conditional
         // load inside the loop hipcc stops counting and falls back to s_waitcnt vmcnt(0).
-        auto groups = [&](const char* wb, int s, const bf16x8 (&pa)[3], bf16x8 (&fb)[2][3]) {
+        auto groups = [&](const char* wb, int s, const V (&pa)[NP], V (&fb)[2][NP]) {
 #pragma unroll
             for (int tn = 0; tn < 8; ++tn) {
                 const int cur = tn & 1, nxt = cur ^ 1;
                 if (s * 8 + tn + 1 < 16 && !(X3_ABLATE & 16)) {  // fragments of the next (step, N-tile), one group ahead
                     const int s2 = (s * 8 + tn + 1) >> 3, t2 = (s * 8 + tn + 1) & 7;
 #pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        fb[nxt][p] = *reinterpret_cast<const bf16x8*>(wb + p * PLANE_BYTES + t2 * 32 * 64 + boff[s2]);
+                    for (int p = 0; p < NP; ++p)
+                        fb[nxt][p] = *reinterpret_cast<const V*>(wb + p * PLANE_BYTES + t2 * 32 * 64 + boff[s2]);
                 }
                 if (X3_ABLATE & 8) {
-                    acc[tn][0] += (float)pa[0][0] + (float)pa[1][1] + (float)pa[2][2] + (float)fb[cur][0][0] +
-                                  (float)fb[cur][1][0] + (float)fb[cur][2][0];
+                    acc[tn][0] += (float)pa[0][0] + (float)pa[NP - 1][1] + (float)fb[cur][0][0] + (float)fb[cur][NP - 1][0];
                     continue;
                 }
-                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[2], fb[cur][0], acc[tn], 0, 0, 0);
-                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], fb[cur][1], acc[tn], 0, 0, 0);
-                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], fb[cur][2], acc[tn], 0, 0, 0);
-                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], fb[cur][0], acc[tn], 0, 0, 0);
-                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], fb[cur][1], acc[tn], 0, 0, 0);
-                acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], fb[cur][0], acc[tn], 0, 0, 0);
-                // first MFMA, then the three prefetch reads, then the other five MFMAs
+                SP::template products<true>(acc[tn], pa, fb[cur], acc[tn]);
+                // first MFMA, then the prefetch reads (one per plane), then the other MFMAs
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, SP::NPROD - 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        auto split_of = [&](const f32x4& lo, const f32x4& hi, bf16x8 (&pa)[3]) {
+        auto split_of = [&](const f32x4& lo, const f32x4& hi, V (&pa)[NP]) {
             if (X3_ABLATE & 32) {
-                pa[0] = __builtin_bit_cast(bf16x8, lo);
-                pa[1] = __builtin_bit_cast(bf16x8, hi);
-                pa[2] = pa[0];
+                pa[0] = __builtin_bit_cast(V, lo);
+                pa[1] = __builtin_bit_cast(V, hi);
+                pa[NP - 1] = pa[0];
+            } else if (SP::SCALED) {
+                split8<SP>(lo * a_scale, hi * a_scale, pa);  // exact: a power of two
             } else {
-                split3(lo, hi, pa[0], pa[1], pa[2]);
+                split8<SP>(lo, hi, pa);
             }
         };
         auto step = [&](auto tail, auto first, int kt, int stage, f32x4 (&ac)[4], f32x4 (&an1)[4], f32x4 (&an2)[4]) {
@@ -255,16 +247,16 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
                 __builtin_amdgcn_sched_barrier(0);
             }
             const char* wb = smem + stage * STAGE_BYTES;
-            bf16x8 fb[2][3];
+            V fb[2][NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) fb[0][p] = *reinterpret_cast<const bf16x8*>(wb + p * PLANE_BYTES + boff[0]);
+            for (int p = 0; p < NP; ++p) fb[0][p] = *reinterpret_cast<const V*>(wb + p * PLANE_BYTES + boff[0]);
             groups(wb, 0, pa_s0, fb);
             STAMP(4 + kt * 4 + 2);
             if (TAIL <= 1 && !(X3_ABLATE & 2)) dma_w(n0, stage ^ 1, kt + 1);
             __builtin_amdgcn_sched_barrier(0);  // the counted waits rely on this issue order: D(kt+1), then A(kt+2)
             if (TAIL == 0 && !(X3_ABLATE & 4)) load_a(an2, kt + 2);
             __builtin_amdgcn_sched_barrier(0);
-            bf16x8 pa_s1[3];
+            V pa_s1[NP];
             asm volatile("" : "+v"(ac[2]));
             asm volatile("" : "+v"(ac[3]));
             split_of(ac[2], ac[3], pa_s1);
@@ -272,7 +264,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
             groups(wb, 1, pa_s1, fb);
             STAMP(4 + kt * 4 + 3);
             if (TAIL <= 1 && !late) {  // A(kt+1) is older than what was requested above: wait for it alone, split its first half
-                if (TAIL == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 10); else __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
+                if (TAIL == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (WPW + 4)); else __builtin_amdgcn_s_waitcnt(0x0F70 | WPW);  // vmcnt only
                 asm volatile("" : "+v"(an1[0]));
                 asm volatile("" : "+v"(an1[1]));
                 split_of(an1[0], an1[1], pa_s0);
@@ -322,6 +314,10 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
                 for (int e = 0; e < 16; ++e) keep += acc[tn][e];
             if (keep == 123.456f) C[0] = keep;
         } else {
+            if (SP::SCALED) {  // back to true units: 2^-(a_exp + w_exp), exact
+#pragma unroll
+                for (int tn = 0; tn < 8; ++tn) acc[tn] *= c_scale;
+            }
             gemm_epilogue<EPI, XWAVES>(acc, slabs, wave, lane, tid, rows_cur, m0_cur, n0_cur, ep, C, ldc);
         }
         STAMP(2);
@@ -330,10 +326,11 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_x3_kernel(const float* __res
     }
 }
 
-// W [N][K] fp32 -> packed planes [3][K/32][N][32] bf16.  Logical chunk c = 2 half + s of a row's 32-deep k-slice holds
+// W [N][K] fp32 (x 2^w_exp for SplitH2) -> packed planes [NP][K/32][N][32] of 16-bit values.  Logical chunk c = 2 half + s of a row's 32-deep k-slice holds
 // the eight contraction indices lane-half `half` owns in step s, k = 8 (2 s + (j >> 2)) + 4 half + (j & 3), and is stored
 // at chunk c ^ ((n >> 2) & 3).  One thread per (n, k-tile, stored chunk).
-__global__ void pack_w_x3_kernel(const float* __restrict__ W, int N, int K, __bf16* __restrict__ out) {
+template <class SP>
+__global__ void pack_w_kernel(const float* __restrict__ W, int N, int K, float w_scale, typename SP::vec* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int KT = K / XBK;
     if (t >= (int64_t)N * KT * 4) return;
@@ -341,42 +338,62 @@ __global__ void pack_w_x3_kernel(const float* __restrict__ W, int N, int K, __bf
     const int c = cs ^ ((n >> 2) & 3);
     const int hf = c >> 1, st = c & 1;
     const float* src = W + (int64_t)n * K + kt * XBK + 16 * st + 4 * hf;  // j = 0..3 here, j = 4..7 eight floats on
-    bf16x8 p0, p1, p2;
-    split3(ld4(src), ld4(src + 8), p0, p1, p2);
-    const int64_t plane = (int64_t)KT * N * XBK;
-    __bf16* dst = out + ((int64_t)kt * N + n) * XBK + cs * 8;
-    *reinterpret_cast<bf16x8*>(dst) = p0;
-    *reinterpret_cast<bf16x8*>(dst + plane) = p1;
-    *reinterpret_cast<bf16x8*>(dst + 2 * plane) = p2;
+    typename SP::vec p[SP::NP];
+    if (SP::SCALED) split8<SP>(ld4(src) * w_scale, ld4(src + 8) * w_scale, p);
+    else split8<SP>(ld4(src), ld4(src + 8), p);
+    const int64_t plane = (int64_t)KT * N * XBK / 8;  // in 16-byte vectors
+#pragma unroll
+    for (int pl = 0; pl < SP::NP; ++pl) out[((int64_t)kt * N + n) * (XBK / 8) + cs + pl * plane] = p[pl];
 }
 
-template <int EPI>
-int launch_x3(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, int64_t M, int N, int K,
-              const EpiArgs& ep, hipStream_t st, bool a_frag = false) {
+struct SplitArgs {
+    int32_t split, a_exp, w_exp;
+};
+
+bool split_args_ok(const SplitArgs& sa) {
+    if (sa.split == SCREAM_SPLIT_BF3) return true;
+    return sa.split == SCREAM_SPLIT_H2 && sa.a_exp >= -60 && sa.a_exp <= 60 && sa.w_exp >= -60 && sa.w_exp <= 60;
+}
+
+template <class SP, int EPI>
+int launch_sp(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, int64_t M, int N, int K, const EpiArgs& ep,
+              hipStream_t st, bool a_frag, const SplitArgs& sa) {
     const int n_tiles = N / XBN;
     const int64_t total = ((M + XBM - 1) / XBM) * n_tiles;
     if (total == 0) return 0;
     SCREAM_REQUIRE(total < (1ll << 31), SCREAM_EUNSUPPORTED);
     const unsigned grid = total < X_MAX_GRID ? (unsigned)total : (unsigned)X_MAX_GRID;
+    const float a_scale = SP::SCALED ? exp2i(sa.a_exp) : 1.f, c_scale = SP::SCALED ? exp2i(-sa.a_exp - sa.w_exp) : 1.f;
     if (a_frag)
-        gemm_x3_kernel<EPI, true><<<dim3(grid), dim3(XTHREADS), 0, st>>>(A, lda, reinterpret_cast<const __bf16*>(Wp), C, ldc, M,
-                                                                         n_tiles, (unsigned)total, N, K, ep);
+        gemm_split_kernel<SP, EPI, true><<<dim3(grid), dim3(XTHREADS), 0, st>>>(A, lda, reinterpret_cast<const char*>(Wp), C, ldc, M, n_tiles,
+                                                                                (unsigned)total, N, K, a_scale, c_scale, ep);
     else
-        gemm_x3_kernel<EPI, false><<<dim3(grid), dim3(XTHREADS), 0, st>>>(A, lda, reinterpret_cast<const __bf16*>(Wp), C, ldc, M,
-                                                                          n_tiles, (unsigned)total, N, K, ep);
+        gemm_split_kernel<SP, EPI, false><<<dim3(grid), dim3(XTHREADS), 0, st>>>(A, lda, reinterpret_cast<const char*>(Wp), C, ldc, M, n_tiles,
+                                                                                 (unsigned)total, N, K, a_scale, c_scale, ep);
     SCREAM_LAUNCH_CHECK();
     return 0;
 }
 
+template <int EPI>
+int launch_split(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, int64_t M, int N, int K, const EpiArgs& ep,
+                 hipStream_t st, bool a_frag, const SplitArgs& sa) {
+    if (sa.split == SCREAM_SPLIT_H2) return launch_sp<SplitH2, EPI>(A, lda, Wp, C, ldc, M, N, K, ep, st, a_frag, sa);
+    return launch_sp<SplitBf3, EPI>(A, lda, Wp, C, ldc, M, N, K, ep, st, a_frag, sa);
+}
+
 }  // namespace
 
-extern "C" int scream_pack_w_x3(const float* W, int32_t N, int32_t K, void* packed, void* stream) {
+extern "C" int scream_pack_w_split(const float* W, int32_t N, int32_t K, int32_t split, int32_t w_exp, void* packed, void* stream) {
     SCREAM_REQUIRE(W && packed, SCREAM_EINVAL);
+    SCREAM_REQUIRE(split_args_ok(SplitArgs{split, 0, w_exp}), SCREAM_EINVAL);
     SCREAM_REQUIRE(N > 0 && N % 4 == 0 && K > 0 && K % XBK == 0, SCREAM_EUNSUPPORTED);
     SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(W) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed) & 15) == 0, SCREAM_EINVAL);
     const int64_t threads = (int64_t)N * (K / XBK) * 4;
-    pack_w_x3_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(
-        W, N, K, reinterpret_cast<__bf16*>(packed));
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    if (split == SCREAM_SPLIT_H2)
+        pack_w_kernel<SplitH2><<<grid, block, 0, as_stream(stream)>>>(W, N, K, exp2i(w_exp), reinterpret_cast<f16x8*>(packed));
+    else
+        pack_w_kernel<SplitBf3><<<grid, block, 0, as_stream(stream)>>>(W, N, K, 1.f, reinterpret_cast<bf16x8*>(packed));
     SCREAM_LAUNCH_CHECK();
     return 0;
 }
@@ -391,14 +408,16 @@ static int check_layout(int32_t layout, int64_t lda, int64_t ldc, int32_t K, int
     return 0;
 }
 
-extern "C" int scream_gemm_x3_ex_f32(const float* A, int64_t lda, const void* W_planes, float* C, int64_t ldc, int64_t M,
+extern "C" int scream_gemm_split_f32(const float* A, int64_t lda, const void* W_packed, float* C, int64_t ldc, int64_t M,
                                      int32_t N, int32_t K, int32_t epilogue, int32_t n_act, const float* bias,
                                      const float* residual, int64_t ldr, const float* gamma, const float* beta,
-                                     int32_t layout, void* stream) {
-    SCREAM_REQUIRE(A && W_planes && C, SCREAM_EINVAL);
+                                     int32_t layout, int32_t split, int32_t a_exp, int32_t w_exp, void* stream) {
+    SCREAM_REQUIRE(A && W_packed && C, SCREAM_EINVAL);
+    const SplitArgs sa{split, a_exp, w_exp};
+    SCREAM_REQUIRE(split_args_ok(sa), SCREAM_EINVAL);
     SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K >= 64 && K % 64 == 0 && (K / 32 - 2) % 3 == 0, SCREAM_EUNSUPPORTED);  // K = 64 + 192 j: an EVEN number of k-tiles (stage = kt & 1), in groups of three after the first two
     SCREAM_REQUIRE(lda >= K && ldc >= N && lda % 4 == 0 && ldc % 4 == 0, SCREAM_EINVAL);
-    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W_planes) & 15) == 0 &&
+    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W_packed) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(C) & 15) == 0, SCREAM_EINVAL);
     if (int rc = check_layout(layout, lda, ldc, K, epilogue, n_act)) return rc;
     const bool af = layout & SCREAM_LAYOUT_A_FRAG;
@@ -406,54 +425,42 @@ extern "C" int scream_gemm_x3_ex_f32(const float* A, int64_t lda, const void* W_
     hipStream_t st = as_stream(stream);
     switch (epilogue) {
         case SCREAM_EPI_NONE:
-            return launch_x3<SCREAM_EPI_NONE>(A, lda, W_planes, C, ldc, M, N, K, ep, st, af);
+            return launch_split<SCREAM_EPI_NONE>(A, lda, W_packed, C, ldc, M, N, K, ep, st, af, sa);
         case SCREAM_EPI_ELU1:
             SCREAM_REQUIRE(n_act >= 0 && n_act % XBN == 0, SCREAM_EUNSUPPORTED);
-            return launch_x3<SCREAM_EPI_ELU1>(A, lda, W_planes, C, ldc, M, N, K, ep, st, af);
+            return launch_split<SCREAM_EPI_ELU1>(A, lda, W_packed, C, ldc, M, N, K, ep, st, af, sa);
         case SCREAM_EPI_RELU:
-            return launch_x3<SCREAM_EPI_RELU>(A, lda, W_planes, C, ldc, M, N, K, ep, st, af);
+            return launch_split<SCREAM_EPI_RELU>(A, lda, W_packed, C, ldc, M, N, K, ep, st, af, sa);
         case SCREAM_EPI_BIAS_RELU:
             SCREAM_REQUIRE(bias, SCREAM_EINVAL);
-            return launch_x3<SCREAM_EPI_BIAS_RELU>(A, lda, W_planes, C, ldc, M, N, K, ep, st, af);
+            return launch_split<SCREAM_EPI_BIAS_RELU>(A, lda, W_packed, C, ldc, M, N, K, ep, st, af, sa);
         case SCREAM_EPI_RES_LN:
             SCREAM_REQUIRE(N == XBN, SCREAM_EUNSUPPORTED);
             SCREAM_REQUIRE(residual && gamma && beta && ldr >= N && ldr % 4 == 0, SCREAM_EINVAL);
             SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(residual) & 15) == 0, SCREAM_EINVAL);
-            return launch_x3<SCREAM_EPI_RES_LN>(A, lda, W_planes, C, ldc, M, N, K, ep, st, af);
+            return launch_split<SCREAM_EPI_RES_LN>(A, lda, W_packed, C, ldc, M, N, K, ep, st, af, sa);
         default:
             return SCREAM_EINVAL;
     }
 }
 
-extern "C" int scream_gemm_x3_f32(const float* A, int64_t lda, const void* W_planes, float* C, int64_t ldc, int64_t M,
-                                  int32_t N, int32_t K, int32_t epilogue, int32_t n_act, const float* bias,
-                                  const float* residual, int64_t ldr, const float* gamma, const float* beta,
-                                  void* stream) {
-    return scream_gemm_x3_ex_f32(A, lda, W_planes, C, ldc, M, N, K, epilogue, n_act, bias, residual, ldr, gamma, beta, 0, stream);
-}
-
-extern "C" int scream_gemm_qkv_x3_ex_f32(const float* A, int64_t lda, const void* W_planes, float* Q, int64_t ldq, int64_t M,
+extern "C" int scream_gemm_qkv_split_f32(const float* A, int64_t lda, const void* W_packed, float* Q, int64_t ldq, int64_t M,
                                          int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
                                          const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
-                                         float* kv_partial, int32_t layout, void* stream) {
-    SCREAM_REQUIRE(A && W_planes && kv_partial && tile_cloud && cloud_row0 && cloud_len, SCREAM_EINVAL);
+                                         float* kv_partial, int32_t layout, int32_t split, int32_t a_exp, int32_t w_exp,
+                                         void* stream) {
+    SCREAM_REQUIRE(A && W_packed && kv_partial && tile_cloud && cloud_row0 && cloud_len, SCREAM_EINVAL);
+    const SplitArgs sa{split, a_exp, w_exp};
+    SCREAM_REQUIRE(split_args_ok(sa), SCREAM_EINVAL);
     SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K >= 64 && K % 64 == 0 && (K / 32 - 2) % 3 == 0, SCREAM_EUNSUPPORTED);  // K = 64 + 192 j
     SCREAM_REQUIRE((n_q == 0 || n_q == XBN) && N == n_q + 2 * XBN && row_base >= 0 && row_base % SCREAM_ROW_TILE == 0,
                    SCREAM_EUNSUPPORTED);
     SCREAM_REQUIRE(n_q == 0 || (Q && ldq >= n_q && ldq % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0), SCREAM_EINVAL);
     SCREAM_REQUIRE(lda >= K && lda % 4 == 0, SCREAM_EINVAL);
-    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W_planes) & 15) == 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W_packed) & 15) == 0, SCREAM_EINVAL);
     SCREAM_REQUIRE(!(layout & SCREAM_LAYOUT_C_FRAG) || n_q == XBN, SCREAM_EUNSUPPORTED);
     if (int rc = check_layout(layout, lda, n_q ? ldq : SCREAM_D_MODEL, K, SCREAM_EPI_QKV, n_q ? n_q : SCREAM_D_MODEL)) return rc;
     EpiArgs ep{n_q, nullptr, nullptr, 0, nullptr, nullptr, kv_partial, tile_cloud, cloud_row0, cloud_len, row_base,
                (layout & SCREAM_LAYOUT_C_FRAG) ? 1 : 0};
-    return launch_x3<SCREAM_EPI_QKV>(A, lda, W_planes, Q, ldq, M, N, K, ep, as_stream(stream), layout & SCREAM_LAYOUT_A_FRAG);
-}
-
-extern "C" int scream_gemm_qkv_x3_f32(const float* A, int64_t lda, const void* W_planes, float* Q, int64_t ldq, int64_t M,
-                                      int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
-                                      const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
-                                      float* kv_partial, void* stream) {
-    return scream_gemm_qkv_x3_ex_f32(A, lda, W_planes, Q, ldq, M, N, K, n_q, tile_cloud, cloud_row0, cloud_len, row_base, kv_partial,
-                                     0, stream);
+    return launch_split<SCREAM_EPI_QKV>(A, lda, W_packed, Q, ldq, M, N, K, ep, as_stream(stream), layout & SCREAM_LAYOUT_A_FRAG, sa);
 }

@@ -1,0 +1,843 @@
+// The row-local tail of an MHAttention block as ONE kernel on the 16-bit matrix cores of gfx950, fp32-accurate by an operand
+// split (split.h: SplitH2, two fp16 planes and three products -- the default since round 3 -- or SplitBf3, three bf16 planes and
+// six products):
+//
+//     att = ((Q' . KV) * Z) * S                 attention apply            (models/transformer.py:41-42)
+//     m1  = LayerNorm1(att . Wm^T + x)          merge + norm1              (:83-84)
+//     y   = LayerNorm2(x + W2 . relu(W1 . m1))  mlp + norm2                (:85-88; the residual is the block INPUT x)
+//
+// Why one kernel.  At the 1400 W socket cap a launch costs what its joules cost; the unfused chain moved
+// 15 KB per row through HBM (att, m1 and the 1024-wide hidden activations twice), each time through an LDS-slab epilogue
+// and an operand re-split.  Here neither att nor m1 nor the hidden activations exist in memory: per row and layer the
+// kernel reads Q' and x (twice) and writes y -- 4 KB.
+//
+// How: everything is computed TRANSPOSED.  The weights are the MFMA A operand (M = output feature), a wave's 32
+// activation rows are the B operand (N = row), so an accumulator holds C^T: lane = activation row, registers = output
+// features.  That IS the B-operand layout of the next GEMM (lane = row, registers = contraction index), so the chain
+//     att_h^T = KV_h^T . Q'_h^T -> (* Z * S, split) -> m^T += Wm[:, h] . att_h^T -> LN1 -> (split)
+//             -> h^T_c = W1[c] . m1^T -> (relu, split) -> y^T += W2[:, c] . h^T_c -> LN2
+// runs with no transposition, LDS round trip or HBM write in between: the contraction index of an MFMA is a dummy, so the
+// fixed permutation between "register i of lane (r, half)" and "feature" is baked into the packed weight images
+// (pack_tail_kernel below).  A LayerNorm is a sum over a lane's 128 registers plus ONE cross-lane add (lanes r and r + 32
+// share a row) instead of a slab transpose and 2 x 32 DPP wave reductions per wave.
+//
+// Geometry: 256 threads = 4 waves, one per SIMD (128 accumulator registers, the operand planes of the wave's m1 rows -- 192
+// registers as bf16 x 3, 128 as fp16 x 2 --, operand buffers), one persistent block per CU, 128 rows per block tile.  The
+// weights stream through a ring of three LDS stages (16 KiB per operand plane) filled by LDS-DMA (global_load_lds_dwordx4);
+// per 128-row tile the ring carries 72 stages: Wm head 0..7, then  W1_0 | W1_c, W2_{c-1} (c = 1 .. 31) | W2_31  -- the same
+// sequence for every row tile, so the ring never drains at a tile boundary.  A stage image is stored exactly as the
+// fragments are read: [plane][fragment][lane][16 B], i.e. every ds_read_b128 and every DMA piece is 1 KiB of contiguous
+// memory, conflict-free without any swizzle.
+//
+// Row operands.  Lane (r, half) needs, of every 128-byte segment of row r, the 16-byte pieces 2a + half.  From a row-major
+// matrix that is a row-per-lane access -- 32 to 64 distinct lines per wave instruction, ~400 cycles of the CU's texture unit
+// each, a quarter of the kernel however the requests were spread (profiles/r02_tail_ablation_*.txt); staged through a
+// wave-private LDS slab by LDS-DMA the lines were full but, with room for one 4 KiB slab per wave, every request had half a
+// stage of lead and the HBM latency showed instead.  So the kernels agree on the layout in HBM: Q', x and y are
+// FRAGMENT-major (SCREAM_ACT_FRAG, include/scream_hip.h) -- per 32-row group and 32-feature segment the pieces are stored
+// [a][lane], i.e. each of a lane's four loads or stores per segment is one contiguous 1 KiB wave access that lands in
+// exactly the registers the MFMA wants, with no LDS in between.  All row operands are inline-asm register loads (hipcc
+// would otherwise wait vmcnt(0) at their first use and drain the weight ring), requested one stage ahead and BEFORE the
+// stage's weight pieces so that the ring's counted wait covers them as well.
+//
+// SplitH2 scales (scream_tail_exps_t, chosen by scream_amd/scales.py so that no operand can leave fp16's range): the att, m1
+// and hidden operands are multiplied by exact powers of two before their split (att: folded into Z; m1: folded into gamma1 /
+// beta1; hidden: one multiply next to the relu), the weight images carry theirs.  The merge and FFN-down accumulators are
+// then c = 2^(e_w + e_a) times the true sums; the residual x joins them as fma(x, c, acc) and the LayerNorm runs on the
+// scaled values with eps c^2 -- bit for bit the LayerNorm of the unscaled values, so no power of two ever costs a rounding.
+// The attention apply itself (12 matrix instructions per head, 3 % of a tile's) stays on the bf16 x 3 split in both
+// instantiations: its KV operand is a data-dependent sum with no useful static bound.
+//
+// Tuning aids (tools/tail_ablate.py builds variants; always 0 in libscream_hip.so): T_ABLATE bit 0 no weight DMA after the
+// first two stages, 1 no MFMAs, 2 no LDS fragment reads, 4 no row loads/stores, 5 no Q', 6 no x, 7 no y stores, 8 no KV
+// operands, 9 no apply rides, 10 no residual adds, 11 every row request goes to the first tile (cache hits).
+#include <type_traits>
+
+#include "ring.h"
+
+// -DT_STAMPS (tools/tail_stamps.py): s_memtime stamps of the phases of the SECOND tile of every block, lane 0 of each wave.
+// Diagnostic build only -- tools/tail_stamps.py runs tools/asm_inflight_check.py on it first: the extra registers can push
+// hipcc into spilling a pending load destination (it did, with one stamp per stage).
+#ifdef T_STAMPS
+#define T_STAMP_SLOTS 24  // 0-5: phase boundaries (64-bit s_memtime); 8-23: low words of the stamps taken at stage tops (TMARK)
+__device__ long long t_stamps[256 * 4 * T_STAMP_SLOTS];
+extern "C" int scream_tail_stamps_read(long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(t_stamps), sizeof(long long) * 256 * 4 * T_STAMP_SLOTS);
+}
+#define TSTAMP(slot)                                                                                 \
+    do {                                                                                             \
+        if (stamp_on && lane == 0) t_stamps[((int)blockIdx.x * 4 + wave) * T_STAMP_SLOTS + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+// a stamp that stays in a scalar register until the tile's end: no memory instruction inside the stages
+#define TMARK(i) marks[i] = (unsigned)__builtin_amdgcn_s_memtime()
+#define TMARK2(i, prev) do { marks[prev] = marks[i]; TMARK(i); } while (0)
+#define TMARKS_FLUSH()                                                                               \
+    do {                                                                                             \
+        if (stamp_on && lane == 0)                                                                   \
+            for (int i_ = 0; i_ < 16; ++i_) t_stamps[((int)blockIdx.x * 4 + wave) * T_STAMP_SLOTS + 8 + i_] = marks[i_]; \
+    } while (0)
+#else
+#define TSTAMP(slot) do {} while (0)
+#define TMARK(i) do {} while (0)
+#define TMARK2(i, prev) do {} while (0)
+#define TMARKS_FLUSH() do {} while (0)
+#endif
+
+namespace {
+
+constexpr int TAIL_STAGES = 72;
+constexpr int KV_PLANES_BYTES = 8 * 3 * 2 * 1024;            // per cloud: [head][plane][step][lane][8] bf16
+constexpr int KV_IMAGE_BYTES = KV_PLANES_BYTES + 8 * 32 * 4;  // + Ksum [head][32] fp32
+
+struct HeadOps {   // the per-cloud operands of one head's apply, as loaded (Q' travels separately: f32x4 q[4], pieces a = 0 .. 3)
+    f32x4 kv[6];   // KV_h^T fragments [plane][step], 16 bytes per lane
+    f32x4 ks[4];   // Ksum[h][8 a + 4 half .. + 4]
+};
+
+// SplitH2: the exact power-of-two factors of the kernel (all 1 / unused for SplitBf3)
+struct TailScales {
+    float s_att;  // 2^e_att, folded into Z
+    float c1;     // 2^(e_wm + e_att): unit of the merge accumulators
+    float eps1;   // 1e-5 c1^2
+    float s_m1;   // 2^e_m1, folded into gamma1 / beta1
+    float ch;     // 2^(e_h - e_w1 - e_m1): FFN-up accumulator -> scaled hidden activation
+    float c2;     // 2^(e_w2 + e_h): unit of the FFN-down accumulators
+    float eps2;   // 1e-5 c2^2
+};
+
+// merge stage h (h >= 1): which quarter of the x-segment add rides in group g (-1: none) -- the last four groups of
+// 14 .. 8 that do not accumulate into tile h - 1
+__device__ __forceinline__ constexpr int xadd_slot(int h, int g) {
+    int n = 0;
+    for (int c = 14; c >= 8; --c) {
+        if ((c >> 1) == h - 1) continue;
+        if (c == g) return n < 4 ? n : -1;
+        ++n;
+    }
+    return -1;
+}
+
+template <class SP>
+__global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q,      // fragment-major [M, 256]
+                                                     const char* __restrict__ kvimg,   // [n_clouds][KV_IMAGE_BYTES]
+                                                     const int32_t* __restrict__ tile_cloud, int kv_cloud_offset,
+                                                     const int32_t* __restrict__ cloud_len,
+                                                     const float* __restrict__ xres,   // fragment-major [M, 256]
+                                                     const char* __restrict__ Wimg,    // [72 stages][NP x 16 KiB]
+                                                     const float* __restrict__ g1, const float* __restrict__ b1,
+                                                     const float* __restrict__ g2, const float* __restrict__ b2,
+                                                     float* __restrict__ y,            // fragment-major [M, 256]
+                                                     int n_tiles, TailScales sc) {
+    typedef typename SP::vec V;
+    constexpr int NP = SP::NP;
+    constexpr int STAGE = stage_bytes<SP>();
+    constexpr int PIECES = wave_pieces<SP>();  // LDS-DMA pieces per wave and stage = what a counted ring wait leaves in flight
+    constexpr int NV_MERGE = SP::NPROD >= 6 ? 6 : 8;  // ride slots behind every MFMA of a merge stage (32 cycles / 4 per VALU issue)
+    __shared__ __attribute__((aligned(16))) char smem[T_SLOTS * STAGE + 4096];  // the ring + the norm parameters, the ONLY LDS object
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    // gamma1 | beta1 | gamma2 | beta2 live in LDS for the whole launch.  Read from global memory inside the norm blocks they
+    // cost more than the arithmetic: on gfx950 loads and stores share vmcnt, hipcc cannot order a load against the y stores
+    // issued before it and waits with vmcnt(0) -- a full store round trip per group of rows (tools/tail_stamps.py: 11.8 k
+    // cycles for norm2 + stores).  From LDS the y stores are fire-and-forget.  (SplitH2: gamma1 / beta1 carry m1's 2^e.)
+    float* lnp = reinterpret_cast<float*>(smem + T_SLOTS * STAGE);
+    lnp[tid] = SP::SCALED ? g1[tid] * sc.s_m1 : g1[tid];
+    lnp[256 + tid] = SP::SCALED ? b1[tid] * sc.s_m1 : b1[tid];
+    lnp[512 + tid] = g2[tid];
+    lnp[768 + tid] = b2[tid];
+    const float eps1 = SP::SCALED ? sc.eps1 : 1e-5f, eps2 = SP::SCALED ? sc.eps2 : 1e-5f;
+    const unsigned v_lane16 = lane * 16, v_half16 = half * 16;  // the only per-lane address parts of the kernel
+    // weight pieces: uniform (scalar) source address + the 32-bit lane offset.  A per-lane 64-bit pointer kept across the
+    // kernel was spilled by hipcc and reloaded from scratch in EVERY stage -- behind a vmcnt(0) that drained the ring.
+    auto dma_piece = [&](unsigned q, int u) {
+        if ((T_ABLATE & 1) && q >= 2) return;
+        const unsigned src = q % (unsigned)TAIL_STAGES, slot = q % (unsigned)T_SLOTS;
+        const char* sbase = Wimg + (size_t)src * STAGE + (wave * PIECES + (u & ~3)) * 1024;
+        dma_1k(sbase + v_lane16, smem + slot * STAGE + (wave * PIECES + (u & ~3)) * 1024, u & 3);
+    };
+    unsigned q = 0;  // next stage to be consumed
+#pragma unroll
+    for (int u = 0; u < PIECES; ++u) dma_piece(0, u);
+#pragma unroll
+    for (int u = 0; u < PIECES; ++u) dma_piece(1, u);
+
+    // ---- row operand requests (inline asm; every consumer sits behind a counted wait + pin) -------------------------
+    // RULE (tools/asm_inflight_check.py enforces it on the generated code): a requested register is consumed at the top
+    // of the NEXT stage, never kept pending across a LayerNorm block -- hipcc, which believes the value present, otherwise
+    // spills it to scratch right behind the asm statement when registers are short there.
+    // grp: first float of the wave's 32-row group (8192 floats in either layout); segment seg, piece a, this lane:
+    // the uniform part of the address of segment seg in the 32-row group starting at float `grp`
+    auto seg_base = [&](const float* base, int64_t grp, int seg) { return base + grp + seg * 1024; };
+    auto req_q = [&](f32x4 (&qb)[4], int64_t grp, int h) {  // Q' of head h: the one operand that comes from HBM
+        if (T_ABLATE & (16 | 32)) return;
+        if (T_ABLATE & 2048) grp = (int64_t)wave * 32 * SCREAM_D_MODEL;  // tuning aid: always the first tile's rows (cache hits)
+        ld_asm4<1024>(qb, seg_base(Q, grp, h), v_lane16);
+    };
+    auto req_head = [&](HeadOps& o, const char* kvc, int h) {  // KV^T fragments and Ksum of head h: L2-hot per-cloud data
+        if (T_ABLATE & (16 | 256)) return;
+        const char* kp = kvc + h * (3 * 2 * 1024);
+        f32x4 (&kv4)[4] = reinterpret_cast<f32x4 (&)[4]>(o.kv[0]);
+        ld_asm4<1024>(kv4, kp, v_lane16);
+        ld_asm2k(o.kv[4], o.kv[5], kp + 4 * 1024, v_lane16);
+        ld_asm4<32>(o.ks, kvc + KV_PLANES_BYTES + 128 * h, v_half16);
+    };
+    auto req_x = [&](f32x4 (&xs)[4], int64_t grp, int blk) {
+        if (T_ABLATE & (16 | 64)) return;
+        if (T_ABLATE & 2048) grp = (int64_t)wave * 32 * SCREAM_D_MODEL;
+        ld_asm4<1024>(xs, seg_base(xres, grp, blk), v_lane16);
+    };
+    auto pin_head = [&](HeadOps& o) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) pin(o.ks[a]);
+#pragma unroll
+        for (int f = 0; f < 6; ++f) pin(o.kv[f]);
+    };
+    // the residual x joins an accumulator tile: plain add, or (SplitH2) fma with the tile's unit c
+    auto add_x4 = [&](f32x16& t, const f32x4 (&xs)[4], int a, float c) {  // one quarter (registers 4a .. 4a + 3)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xv = (T_ABLATE & 16) ? 1.0f : xs[a][k];
+            t[4 * a + k] = SP::SCALED ? __builtin_fmaf(xv, c, t[4 * a + k]) : t[4 * a + k] + xv;
+        }
+    };
+    auto pin_x = [&](f32x4 (&xs)[4]) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) pin(xs[a]);
+    };
+    auto add_x = [&](f32x16& t, const f32x4 (&xs)[4], float c) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) add_x4(t, xs, a, c);
+    };
+
+    // KV^T / Ksum: ONE buffer, consumed in a stage's first groups and re-requested right after (a third of a stage of
+    // lead is plenty for L2-hot data).  Q' comes from HBM and gets TWO buffers, alternating by head, requested at the
+    // top of the stage BEFORE the one that consumes it -- with a single buffer the merge stages took 6.6 k cycles against
+    // 3.8 k for an FFN stage (tools/tail_stamps.py).
+    HeadOps op;
+    f32x4 qA[4], qB[4];     // Q' of even / odd heads
+    f32x4 xs[4], xs2[4];    // x segments (xs2: only segment 7 of the norm1 residual)
+    V apA[2][NP], apB[2][NP];  // planes of att_h^T, the B operand of the merge GEMM: heads of even / odd index
+    f32x16 aT;              // att_h^T tile of the head being applied
+    bf16x8 qp[2][3];        // the apply runs on SplitBf3 in both instantiations
+    float Zs = 0.f;
+
+    // ---- apply of one head (models/transformer.py:41-42), in pieces that ride inside the groups of another stage ----
+    auto apply_qsplit = [&](f32x4 (&qb)[4], int tile_tag, int s2) {  // 16-deep step s2 of Q' into its three planes
+        if (T_ABLATE & 16) {
+            const f32x4 f = {(float)lane, 1.0f, 0.5f, (float)tile_tag};
+            split8<SplitBf3>(f, f, qp[s2]);
+            return;
+        }
+        split8<SplitBf3>(qb[2 * s2], qb[2 * s2 + 1], qp[s2]);
+    };
+    auto apply_mfma = [&](int s2) {
+        bf16x8 w[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) w[p] = __builtin_bit_cast(bf16x8, op.kv[p * 2 + s2]);
+        mfma_group<SplitBf3, -1>(aT, w, qp[s2], s2 == 0);
+    };
+    auto apply_z = [&](f32x4 (&qb)[4]) {  // Z = 1 / (Q'.Ksum + 1e-6); lanes r and r + 32 share row r
+        float zp = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) zp += qb[a][k] * op.ks[a][k];
+        zp += __shfl_xor(zp, 32);
+        Zs = 1.0f / (zp + 1e-6f);
+        if (SP::SCALED) Zs *= sc.s_att;  // exact; (aT * (Z 2^e)) * S == ((aT * Z) * S) 2^e bit for bit
+    };
+    auto apply_split_pair = [&](int k, V (&ap)[2][NP], float S) {  // elements 2k, 2k+1: (aT * Z) * S, then the operand split
+        const int s2 = k >> 2, j = (2 * k) & 7;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) SP::split1((aT[2 * k + e] * Zs) * S, j + e, ap[s2]);
+    };
+    // the pieces of one apply as they ride in group g of a 16-group stage: operands consumed in groups 0-3
+    auto apply_ride = [&](f32x4 (&qb)[4], int g, V (&ap)[2][NP], float S, int tile_tag) {
+        if (g == 0) apply_qsplit(qb, tile_tag, 0);
+        if (g == 1) apply_qsplit(qb, tile_tag, 1);
+        if (g == 1) apply_mfma(0);
+        if (g == 2) apply_mfma(1);
+        if (g == 3) apply_z(qb);
+        if (g >= 4 && g < 12) apply_split_pair(g - 4, ap, S);
+    };
+
+    int tile = blockIdx.x;
+    int64_t grp = ((int64_t)tile * 128 + wave * 32) * SCREAM_D_MODEL;  // first float of this wave's 32-row group
+    const char* kvc = nullptr;
+    float S = 1.f;
+    if (tile < n_tiles) {  // the block's first tile: heads 0 and 1 are applied in the open (once per block)
+        const int cl = tile_cloud[tile] + kv_cloud_offset;
+        kvc = kvimg + (size_t)cl * KV_IMAGE_BYTES;
+        S = (float)cloud_len[cl];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            req_q(qA, grp, h);
+            req_head(op, kvc, h);
+            VM_WAIT(0);
+            pin_x(qA);
+            pin_head(op);
+#pragma unroll
+            for (int g = 0; g < 12; ++g) apply_ride(qA, g, h == 0 ? apA : apB, S, tile);
+        }
+    }
+
+#ifdef T_STAMPS
+    int tile_no = 0;
+#endif
+    while (tile < n_tiles) {
+#ifdef T_STAMPS
+        const bool stamp_on = tile_no == 1;
+        ++tile_no;
+        unsigned marks[16] = {};
+#endif
+        TSTAMP(0);  // tile start
+        // The last MFMA group of every stage is DEFERRED across the barrier: its weight fragments are read into wfd, and
+        // the next stage issues it right after the first fragment reads of its own -- a group of work with register
+        // operands exactly where a lone in-order wave otherwise waits for the LDS (tools/tail_stamps.py: 3.8 k cycles per
+        // 3.07 k-cycle stage of the bf16 kernel).  `flush` arguments below name the deferred group of the preceding stage.
+        V wfd[NP];
+        f32x16 acc[8];  // (started by the first product of merge stage 0 / of the first down stage: no zeroing moves)
+        // the block's next tile (its heads 0 and 1 are applied under / right after this tile's last stage)
+        const int tile_next = tile + (int)gridDim.x;
+        const bool has_next = tile_next < n_tiles;
+        // (the last tile of a block "requests" its own operands again instead of branching around the requests: an asm load
+        // that is skipped on one path leaves the buffer's OLD contents live across the whole FFN phase -- 40 spilled registers)
+        const int64_t grp_next = ((int64_t)(has_next ? tile_next : tile) * 128 + wave * 32) * SCREAM_D_MODEL;
+        const char* kvc_next = kvc;
+        float S_next = 1.f;
+        if (has_next) {
+            const int cl = tile_cloud[tile_next] + kv_cloud_offset;
+            kvc_next = kvimg + (size_t)cl * KV_IMAGE_BYTES;
+            S_next = (float)cloud_len[cl];
+        }
+
+        // merge stage of head h: m^T += Wm[:, head h] . att_h^T with att_h's planes in `ap` (heads 0, 1: applied during the
+        // previous tile).
+        //   top:         x segment h - 1 (the norm1 residual, requested by stage h - 1) is added into accumulator tile h - 1,
+        //                then segment h is requested (stage 6 also requests segment 7, stage 7 adds both);
+        //   groups 0-3:  stages 1 .. 6 consume the operands of head h + 1 (requested by stage h - 1) -- its apply rides here;
+        //   group 4:     the operand buffer is re-requested for head h + 2 (stage 0: requested at the top);
+        //   groups 4-15: the stage's weight pieces, AFTER every row request, so that the next barrier's counted wait covers them.
+        auto stage_merge = [&](auto hh, V (&ap)[2][NP], V (&ap_next)[2][NP], f32x4 (&q_cons)[4], f32x4 (&q_req)[4], auto flush) {
+            constexpr int h = decltype(hh)::value;
+            constexpr bool RIDE = h >= 1 && h <= 6;
+            // stage 0 of a tile: everything older was drained at the end of the previous tile (only its y stores may
+            // still be in flight, and nothing of this stage depends on them)
+            if (h == 0) lds_only_barrier(); else ring_barrier<PIECES>();
+            TMARK(h);  // T_STAMPS builds: marks 0-7 = the tops of the merge stages
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 (&x_prev)[4] = (h & 1) ? xs : xs2;   // segment h - 1 (landed: requested by stage h - 1)
+            f32x4 (&x_req)[4] = (h & 1) ? xs2 : xs;    // segment h
+            if (h > 0) {
+                pin_x(x_prev);
+                if (RIDE) {
+                    pin_head(op);
+                    pin_x(q_cons);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            req_x(x_req, grp, h);
+            if (h + 2 < 8) req_q(q_req, grp, h + 2);  // consumed by stage h + 1
+            if (h == 0) req_head(op, kvc, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            const char* wb = smem + (q % T_SLOTS) * STAGE + lane * 16;
+            V wf[T_PF][NP];
+#pragma unroll
+            for (int g0 = 0; g0 < T_PF - 1; ++g0)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) wf[g0][p] = ld_frag<V>(wb + (p * 16 + g0) * 1024);
+            flush();
+#pragma unroll
+            for (int g = 0; g < 15; ++g) {  // g = blk * 2 + s2; group 15 is deferred to the next stage
+                if (g + T_PF - 1 < 16) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        (g + T_PF - 1 == 15 ? wfd[p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag<V>(wb + (p * 16 + g + T_PF - 1) * 1024);
+                }
+                if (g == 4 && RIDE && h + 2 < 8) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    req_head(op, kvc, h + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (g >= 4 && g - 4 < PIECES) dma_piece(q + 2, g - 4);
+                if (PIECES == 12 && g == 14) dma_piece(q + 2, 11);  // (group 15 is deferred: the twelfth piece goes out with the eleventh)
+                if (RIDE && !(T_ABLATE & 512)) apply_ride(q_cons, g, ap_next, S, tile);
+                // the norm1 residual: segment h - 1 joins accumulator tile h - 1 in quarters, in late groups that do not
+                // accumulate into that tile (its MFMAs are groups 2h - 2 and 2h - 1)
+                if (h > 0) {
+                    const int pc = xadd_slot(h, g);
+                    if (pc >= 0 && !(T_ABLATE & 1024)) add_x4(acc[h > 0 ? h - 1 : 0], x_prev, pc, sc.c1);
+                }
+                mfma_group<SP, (h > 0 ? NV_MERGE : 0)>(acc[g >> 1], wf[g % T_PF], ap[g & 1], h == 0 && (g & 1) == 0);
+            }
+            ++q;
+        };
+        constexpr std::integral_constant<bool, true> yes{};
+        constexpr std::integral_constant<bool, false> no{};
+#define HEAD(n) std::integral_constant<int, n>{}
+        auto flush_none = [&]() {};
+        auto flush_mergeA = [&]() { mfma_group<SP, -1>(acc[7], wfd, apA[1]); };  // deferred group of a merge stage of an even head
+        auto flush_mergeB = [&]() { mfma_group<SP, -1>(acc[7], wfd, apB[1]); };
+        //            head   planes  planes of head + 1   Q' consumed (head + 1)   Q' requested (head + 2)   deferred group of
+        stage_merge(HEAD(0), apA, apB, qB, qA, flush_none);   // (the previous tile ended flushed)
+        stage_merge(HEAD(1), apB, apA, qA, qB, flush_mergeA);
+        stage_merge(HEAD(2), apA, apB, qB, qA, flush_mergeB);
+        stage_merge(HEAD(3), apB, apA, qA, qB, flush_mergeA);
+        stage_merge(HEAD(4), apA, apB, qB, qA, flush_mergeB);
+        stage_merge(HEAD(5), apB, apA, qA, qB, flush_mergeA);
+        stage_merge(HEAD(6), apA, apB, qB, qA, flush_mergeB);
+        stage_merge(HEAD(7), apB, apA, qA, qB, flush_mergeA);
+        flush_mergeB();  // norm1 needs the finished accumulators
+        vm_wait<PIECES>();  // x segment 7 (requested at the top of stage 7, older than that stage's weight pieces)
+        pin_x(xs2);
+        add_x(acc[7], xs2, sc.c1);
+
+        TSTAMP(1);  // end of the merge phase
+        // ---- m1 = LayerNorm1(merge + x) (models/transformer.py:84), straight into the B-operand planes of FFN-up ---
+        V mp[16][NP];
+        {
+            float sum = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum += acc[b][e];
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / 256.0f);
+            float var = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    acc[b][e] -= mean;
+                    var += acc[b][e] * acc[b][e];
+                }
+            var += __shfl_xor(var, 32);
+            const float rstd = 1.0f / sqrtf(var * (1.0f / 256.0f) + eps1);
+            const float* gp = lnp + 4 * half;
+            const float* bp = lnp + 256 + 4 * half;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    f32x4 v[2];
+#pragma unroll
+                    for (int a2 = 0; a2 < 2; ++a2) {
+                        const int a = 2 * s2 + a2;
+                        const f32x4 g4 = ld4(gp + 32 * b + 8 * a), b4 = ld4(bp + 32 * b + 8 * a);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[a2][k] = acc[b][4 * a + k] * rstd * g4[k] + b4[k];
+                    }
+                    split8<SP>(v[0], v[1], mp[2 * b + s2]);
+                }
+        }
+
+        TSTAMP(2);  // end of norm1
+        // ---- FFN; x segments 0 .. 7 (the norm2 residual) are added under the first eight down stages
+        f32x16 hT;
+        V hpA[2][NP], hpB[2][NP];
+        // relu + split of elements 2k, 2k+1 of the finished h^T tile into the B-operand planes of the down GEMM
+        auto split_pair = [&](int k, V (&hout)[2][NP]) {
+            const int s2 = k >> 2, j = (2 * k) & 7;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float x = fmaxf(hT[2 * k + e], 0.f);
+                SP::split1(SP::SCALED ? x * sc.ch : x, j + e, hout[s2]);
+            }
+        };
+        // XLOAD: x segment to request in this stage (-1: none)
+        auto stage_up = [&](auto first, auto xload, auto flush) {
+            constexpr int XLOAD = decltype(xload)::value;
+            // FIRST: the norm1 block above used ordinary loads (gamma, beta), which hipcc waits for with vmcnt(0)
+            if (decltype(first)::value) ring_barrier<0>(); else ring_barrier<PIECES>();
+            TMARK2(8, 10);  // T_STAMPS builds: tops of the last two up stages
+            __builtin_amdgcn_sched_barrier(0);
+            if (XLOAD >= 0) req_x(xs, grp, XLOAD);
+            __builtin_amdgcn_sched_barrier(0);
+            const char* wb = smem + (q % T_SLOTS) * STAGE + lane * 16;
+            V wf[T_PF][NP];
+#pragma unroll
+            for (int g0 = 0; g0 < T_PF - 1; ++g0)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) wf[g0][p] = ld_frag<V>(wb + (p * 16 + g0) * 1024);
+            flush();
+#pragma unroll
+            for (int g = 0; g < 15; ++g) {  // group 15 (hT += wfd . mp[15]) is deferred to the next stage
+                if (g + T_PF - 1 < 16) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        (g + T_PF - 1 == 15 ? wfd[p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag<V>(wb + (p * 16 + g + T_PF - 1) * 1024);
+                }
+                if (g < PIECES) dma_piece(q + 2, g);
+                mfma_group<SP>(hT, wf[g % T_PF], mp[g], g == 0);
+            }
+            ++q;
+        };
+        // XADD: x segment (requested by the previous stage) to add into its accumulator tile (-1: none).
+        // RIDE (the tile's last two stages, when the FFN's operand planes are dead and registers are available again):
+        // 1 = requests the operands of the next tile's head 0; 2 = the apply of that head rides here, and head 1 is
+        // requested behind it (applied in the open right after the stage).
+        auto stage_down = [&](V (&hin)[2][NP], V (&hout)[2][NP], auto with_split, auto xadd, auto ride, auto flush) {
+            constexpr int XADD = decltype(xadd)::value;
+            constexpr int RIDE = decltype(ride)::value;
+            ring_barrier<PIECES>();
+            TMARK2(9, 11);  // ... and of the last two down stages
+            __builtin_amdgcn_sched_barrier(0);
+            if (XADD == 0) {  // the tile's first down stage starts the accumulators: tile 0 from its x segment, the others from 0
+                pin_x(xs);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float xv = (T_ABLATE & 16) ? 1.0f : xs[a][k];
+                        acc[0][4 * a + k] = SP::SCALED ? xv * sc.c2 : xv;
+                    }
+            } else if (XADD > 0) {
+                pin_x(xs);
+                add_x(acc[XADD > 0 ? XADD : 0], xs, sc.c2);
+            }
+            if (RIDE == 2) {  // (untouched registers when the block has no next tile: the results are never used)
+                pin_head(op);
+                pin_x(qA);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (RIDE == 1) {
+                req_q(qA, grp_next, 0);
+                req_head(op, kvc_next, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const char* wb = smem + (q % T_SLOTS) * STAGE + lane * 16;
+            V wf[T_PF][NP];
+#pragma unroll
+            for (int g0 = 0; g0 < T_PF - 1; ++g0)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) wf[g0][p] = ld_frag<V>(wb + (p * 16 + g0) * 1024);
+            flush();
+#pragma unroll
+            for (int g = 0; g < 15; ++g) {  // g = blk * 2 + s2; group 15 (acc[7] += wfd . hin[1]) is deferred to the next stage
+                if (g + T_PF - 1 < 16) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        (g + T_PF - 1 == 15 ? wfd[p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag<V>(wb + (p * 16 + g + T_PF - 1) * 1024);
+                }
+                if (RIDE == 2 && g == 4) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    req_q(qA, grp_next, 1);  // head 1 into the buffers head 0 has just left (a second Q' buffer here, at the
+                    req_head(op, kvc_next, 1);  // top of the stage, was spilled by hipcc right behind its loads)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (RIDE == 2) {
+                    if (g >= 4 && g - 4 < PIECES) dma_piece(q + 2, g - 4);
+                    if (PIECES == 12 && g == 14) dma_piece(q + 2, 11);  // (group 15 is deferred: the twelfth piece goes out with the eleventh)
+                } else {
+                    if (g < PIECES) dma_piece(q + 2, g);
+                }
+                if (RIDE == 2) apply_ride(qA, g, apA, S_next, tile_next);
+                if (decltype(with_split)::value && (g & 1) == 0) split_pair(g >> 1, hout);
+                mfma_group<SP>(acc[g >> 1], wf[g % T_PF], hin[g & 1], XADD == 0 && g >= 2 && (g & 1) == 0);
+            }
+            ++q;
+        };
+        constexpr std::integral_constant<int, -1> none{};
+        constexpr std::integral_constant<int, 0> ride0{};
+        // stage order (= image order): W1_0 | W1_c, W2_{c-1} for c = 1 .. 31 | W2_31.  The norm2 residual: the up stage of
+        // chunk c requests x segment c - 1, the down stage of chunk c - 1 that follows adds it (c - 1 < 8) -- the first
+        // four pair iterations are peeled so that every accumulator index is a compile-time constant.
+        auto flush_up = [&]() { mfma_group<SP, -1>(hT, wfd, mp[15]); };            // deferred group of an up stage
+        auto flush_downA = [&]() { mfma_group<SP, -1>(acc[7], wfd, hpA[1]); };     // ... of a down stage whose operand was hpA
+        auto flush_downB = [&]() { mfma_group<SP, -1>(acc[7], wfd, hpB[1]); };
+        stage_up(yes, none, flush_none);
+        flush_up();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) split_pair(k, hpA);
+#define PAIR(c, fl, flA)                                                                    \
+        stage_up(no, HEAD((c) - 1), fl);                           /* chunk c */             \
+        stage_down(hpA, hpB, yes, HEAD((c) - 1), ride0, flush_up); /* chunk c - 1, splits c */ \
+        stage_up(no, HEAD(c), flA);                                /* chunk c + 1 */         \
+        stage_down(hpB, hpA, yes, HEAD(c), ride0, flush_up);       /* chunk c, splits c + 1 */
+        PAIR(1, flush_none, flush_downA) PAIR(3, flush_downB, flush_downA) PAIR(5, flush_downB, flush_downA) PAIR(7, flush_downB, flush_downA)
+#undef PAIR
+        for (int c = 9; c < 31; c += 2) {
+            stage_up(no, none, flush_downB);
+            stage_down(hpA, hpB, yes, none, ride0, flush_up);
+            stage_up(no, none, flush_downA);
+            stage_down(hpB, hpA, yes, none, ride0, flush_up);
+        }
+        stage_up(no, none, flush_downB);                           // chunk 31
+        stage_down(hpA, hpB, yes, none, HEAD(1), flush_up);         // chunk 30, splitting chunk 31; requests head 0 of the block's next tile
+        stage_down(hpB, hpA, no, none, HEAD(2), flush_downA);       // chunk 31; applies that head, requests head 1
+        flush_downB();                                              // norm2 needs the finished accumulators
+#undef HEAD
+        // Drain: the ring's two stages in flight and head 1 of the next tile, requested two thirds of a stage ago.  That
+        // head is applied here in the open (12 MFMAs), so that nothing pending lives across the norm2 block, and the y
+        // stores below are YOUNGER than every load a later counted wait is meant to cover (stores retire out of order with
+        // respect to loads, gemm_split.hip; stage 0 of the next tile starts without a vector-memory wait).
+        TSTAMP(3);  // end of the last stage
+        VM_WAIT(0);
+        if (has_next) {
+            pin_head(op);
+            pin_x(qA);
+#pragma unroll
+            for (int g = 0; g < 12; ++g) apply_ride(qA, g, apB, S_next, tile_next);
+        }
+
+        TSTAMP(4);  // after the open apply of the next tile's head 1
+        // ---- y = LayerNorm2(x + ffn) (the residual is already in the accumulators), stored fragment-major ------------
+        {
+            float sum = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum += acc[b][e];
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / 256.0f);
+            float var = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    acc[b][e] -= mean;
+                    var += acc[b][e] * acc[b][e];
+                }
+            var += __shfl_xor(var, 32);
+            const float rstd = 1.0f / sqrtf(var * (1.0f / 256.0f) + eps2);
+            const float* gp = lnp + 512 + 4 * half;
+            const float* bp = lnp + 768 + 4 * half;
+            float* yg = y + grp + lane * 4;  // (uniform base + lane: the stores below differ by immediates and scalar adds)
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const f32x4 g4 = ld4(gp + 32 * b + 8 * a), b4 = ld4(bp + 32 * b + 8 * a);
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = acc[b][4 * a + k] * rstd * g4[k] + b4[k];
+                    // one contiguous 1 KiB per wave instruction
+                    if (!(T_ABLATE & (16 | 128)) || o[0] + o[1] + o[2] + o[3] == 123.456f) *reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256) = o;
+                }
+        }
+        TSTAMP(5);  // tile end
+        TMARKS_FLUSH();
+        tile = tile_next;
+        grp = ((int64_t)tile_next * 128 + wave * 32) * SCREAM_D_MODEL;
+        kvc = kvc_next;
+        S = S_next;
+    }
+    VM_WAIT(0);  // the two stages requested past the end must have landed before the LDS is released
+}
+
+// [M, 256] fp32 row-major <-> fragment-major (SCREAM_ACT_FRAG, include/scream_hip.h).  One block per 32-row group: the
+// group is read in full lines, turned around in LDS and written in full lines.  Boundary use only (after the embedding,
+// for tests and for callers that hold row-major data).
+__global__ __launch_bounds__(256) void act_layout_kernel(const float* __restrict__ src, float* __restrict__ dst, int to_frag) {
+    __shared__ float tile[32][260];  // +4: the transposing accesses below touch rows 1040 bytes apart
+    const int t = threadIdx.x;
+    const float* s = src + (int64_t)blockIdx.x * 8192;
+    float* d = dst + (int64_t)blockIdx.x * 8192;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = t + 256 * i;  // float4 index inside the group
+        const f32x4 v = *reinterpret_cast<const f32x4*>(s + e * 4);
+        int row, col;
+        if (to_frag) {
+            row = e >> 6, col = (e & 63) * 4;  // source is row-major
+        } else {
+            const int ln = e & 63, a = (e >> 6) & 3, blk = e >> 8;  // source is fragment-major
+            row = ln & 31, col = 32 * blk + 8 * a + 4 * (ln >> 5);
+        }
+        *reinterpret_cast<f32x4*>(&tile[row][col]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = t + 256 * i;
+        int row, col;
+        if (to_frag) {
+            const int ln = e & 63, a = (e >> 6) & 3, blk = e >> 8;
+            row = ln & 31, col = 32 * blk + 8 * a + 4 * (ln >> 5);
+        } else {
+            row = e >> 6, col = (e & 63) * 4;
+        }
+        *reinterpret_cast<f32x4*>(d + e * 4) = *reinterpret_cast<const f32x4*>(&tile[row][col]);
+    }
+}
+
+// Wm [256][256], W1 [1024][256], W2 [256][1024] fp32 -> the 72 stage images of tail_kernel<SP>,
+// [72][SP::NP planes][16 fragments][64 lanes][8] 16-bit values, in the order the kernel consumes them: merge head h (stage h)
+// is "W2 chunk h" of a 256-deep matrix; stages 8 .. 71 are  W1_0 | W1_c, W2_{c-1} (c = 1 .. 31) | W2_31.  A-operand row
+// m = lane & 31 of fragment frag = 2 blk + s2 is output feature 32 blk + m (down / merge) or hidden unit 32 c + m (up); its
+// eight values are contraction indices chunk_k(s2, half, 0 .. 7) of the stage's 32-wide chunk.  SplitH2: every matrix is
+// multiplied by its exact 2^e first.  One thread per (stage, fragment, lane).
+template <class SP>
+__global__ void pack_tail_kernel(const float* __restrict__ Wm, const float* __restrict__ W1, const float* __restrict__ W2,
+                                 float s_wm, float s_w1, float s_w2, typename SP::vec* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= TAIL_STAGES * 16 * 64) return;
+    const int lane = t & 63, frag = (t >> 6) & 15, stage = t >> 10;
+    const int m = lane & 31, half = lane >> 5;
+    float v[8];
+    float s;
+    if (stage < 8) {
+        s = s_wm;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Wm[(int64_t)(32 * (frag >> 1) + m) * 256 + 32 * stage + chunk_k(frag & 1, half, j)];
+    } else {
+        const int st = stage - 8;
+        const bool up = st == 0 || (st < 63 && (st & 1));
+        const int c = st == 0 ? 0 : st == 63 ? 31 : up ? (st + 1) / 2 : st / 2 - 1;
+        s = up ? s_w1 : s_w2;
+        if (up) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = W1[(int64_t)(32 * c + m) * 256 + 32 * (frag >> 1) + chunk_k(frag & 1, half, j)];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = W2[(int64_t)(32 * (frag >> 1) + m) * 1024 + 32 * c + chunk_k(frag & 1, half, j)];
+        }
+    }
+    typename SP::vec p[SP::NP];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) SP::split1(SP::SCALED ? v[j] * s : v[j], j, p);
+#pragma unroll
+    for (int pl = 0; pl < SP::NP; ++pl) out[(((int64_t)stage * SP::NP + pl) * 16 + frag) * 64 + lane] = p[pl];
+}
+
+// Sum of the per-128-row-tile K^T V partials of the fused q/k/v GEMM (as kv_finalize_tiles_kernel, attention.hip) written
+// as the operand image of tail_kernel: per cloud and head the A-operand fragments of KV_h^T / S (row m = value index
+// v, contraction index d = chunk_k(step, half, j)) in three bf16 planes, then Ksum as fp32.  grid n_kv * 8, block 1024.
+__global__ __launch_bounds__(1024) void kv_finalize_x3_kernel(const float* __restrict__ partial,
+                                                            const int32_t* __restrict__ cloud_row0,
+                                                            const int32_t* __restrict__ cloud_len, int64_t row_base,
+                                                            int cloud_begin, char* __restrict__ kvimg) {
+    constexpr int KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;
+    const int kvi = blockIdx.x / SCREAM_NHEAD, h = blockIdx.x % SCREAM_NHEAD;
+    const int cloud = cloud_begin + kvi;
+    const int t0 = (int)((cloud_row0[cloud] - row_base) / SCREAM_ROW_TILE);
+    const int nt = (cloud_len[cloud] + SCREAM_ROW_TILE - 1) / SCREAM_ROW_TILE;
+    const float* p = partial + ((int64_t)t0 * SCREAM_NHEAD + h) * KV_ELEMS;
+    char* img = kvimg + (size_t)cloud * KV_IMAGE_BYTES;
+    const float S = (float)cloud_len[cloud];
+    for (int i = threadIdx.x; i < KV_ELEMS; i += 1024) {
+        float s8[16];  // sixteen chains in a fixed combination order: deterministic (same order as kv_finalize_tiles_kernel)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s8[u] = 0.f;
+        for (int c = 0; c < nt; c += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (c + u < nt) s8[u] += p[(int64_t)(c + u) * SCREAM_NHEAD * KV_ELEMS + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += s8[u + 8];
+        const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        if (i < 32 * 32) {
+            const int d = i >> 5, v = i & 31;             // partial layout [d][v]
+            const float x = s / S;                         // values / v_length (models/transformer.py:38-39), applied to the sum
+            const int s2 = d >> 4, hf = (d >> 2) & 1, j = 4 * ((d >> 3) & 1) + (d & 3);  // d = chunk_k(s2, hf, j)
+            const __bf16 a = (__bf16)x;
+            const float r1 = x - (float)a;
+            const __bf16 b = (__bf16)r1;
+            const __bf16 cc = (__bf16)(r1 - (float)b);
+            __bf16* base = reinterpret_cast<__bf16*>(img) + ((size_t)(h * 3) * 2 + s2) * 512 + (v + 32 * hf) * 8 + j;
+            base[0] = a;
+            base[2 * 512] = b;
+            base[4 * 512] = cc;
+        } else {
+            reinterpret_cast<float*>(img + KV_PLANES_BYTES)[h * 32 + (i - 32 * 32)] = s;
+        }
+    }
+}
+
+bool split_ok(int32_t split) { return split == SCREAM_SPLIT_BF3 || split == SCREAM_SPLIT_H2; }
+
+// the kernel's factors from the six exponents; false if one leaves the range the arithmetic was checked for
+bool tail_scales(const scream_tail_exps_t* ex, TailScales* sc) {
+    if (!ex) return false;
+    const int es[6] = {ex->e_att, ex->e_wm, ex->e_m1, ex->e_w1, ex->e_h, ex->e_w2};
+    for (int e : es)
+        if (e < -40 || e > 40) return false;
+    const int e1 = ex->e_wm + ex->e_att, e2 = ex->e_w2 + ex->e_h, eh = ex->e_h - ex->e_w1 - ex->e_m1;
+    if (e1 < -44 || e1 > 44 || e2 < -44 || e2 > 44 || eh < -100 || eh > 100) return false;  // c^2 and c^2 * var stay finite in fp32
+    sc->s_att = exp2i(ex->e_att);
+    sc->c1 = exp2i(e1);
+    sc->eps1 = 1e-5f * exp2i(2 * e1);
+    sc->s_m1 = exp2i(ex->e_m1);
+    sc->ch = exp2i(eh);
+    sc->c2 = exp2i(e2);
+    sc->eps2 = 1e-5f * exp2i(2 * e2);
+    return true;
+}
+
+}  // namespace
+
+extern "C" int64_t scream_tail_image_bytes(int32_t split) {
+    if (!split_ok(split)) return SCREAM_EINVAL;
+    return (int64_t)TAIL_STAGES * split * 16 * 1024;
+}
+extern "C" int64_t scream_kv_image_bytes(void) { return KV_IMAGE_BYTES; }
+
+extern "C" int scream_pack_tail(const float* Wm, const float* W1, const float* W2, int32_t split, const scream_tail_exps_t* exps,
+                                void* image, void* stream) {
+    SCREAM_REQUIRE(Wm && W1 && W2 && image && split_ok(split), SCREAM_EINVAL);
+    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, SCREAM_EINVAL);
+    const dim3 grid(TAIL_STAGES * 16 * 64 / 256), block(256);
+    if (split == SCREAM_SPLIT_H2) {
+        TailScales sc;
+        SCREAM_REQUIRE(tail_scales(exps, &sc), SCREAM_EINVAL);
+        pack_tail_kernel<SplitH2><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, exp2i(exps->e_wm), exp2i(exps->e_w1), exp2i(exps->e_w2),
+                                                                         reinterpret_cast<f16x8*>(image));
+    } else {
+        pack_tail_kernel<SplitBf3><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, 1.f, 1.f, 1.f, reinterpret_cast<bf16x8*>(image));
+    }
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int scream_kv_finalize_x3(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
+                                     int64_t row_base, int32_t cloud_begin, int32_t n_kv, void* kv_image, void* stream) {
+    SCREAM_REQUIRE(kv_partial && cloud_row0 && cloud_len && kv_image, SCREAM_EINVAL);
+    SCREAM_REQUIRE(n_kv >= 0 && cloud_begin >= 0 && row_base >= 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(kv_image) & 15) == 0, SCREAM_EINVAL);
+    if (n_kv == 0) return 0;
+    kv_finalize_x3_kernel<<<dim3(n_kv * SCREAM_NHEAD), dim3(1024), 0, as_stream(stream)>>>(kv_partial, cloud_row0, cloud_len, row_base,
+                                                                                         cloud_begin, reinterpret_cast<char*>(kv_image));
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int scream_layer_tail_f32(const float* Q, const void* kv_image, const int32_t* tile_cloud,
+                                     int32_t kv_cloud_offset, const int32_t* cloud_len, const float* x,
+                                     const void* tail_image, const float* g1, const float* b1, const float* g2,
+                                     const float* b2, float* y, int64_t M, int32_t split, const scream_tail_exps_t* exps,
+                                     void* stream) {
+    SCREAM_REQUIRE(Q && kv_image && tile_cloud && cloud_len && x && tail_image && g1 && b1 && g2 && b2 && y && split_ok(split), SCREAM_EINVAL);
+    SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE(((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(kv_image) | reinterpret_cast<uintptr_t>(x) |
+                     reinterpret_cast<uintptr_t>(tail_image) | reinterpret_cast<uintptr_t>(g1) | reinterpret_cast<uintptr_t>(b1) |
+                     reinterpret_cast<uintptr_t>(g2) | reinterpret_cast<uintptr_t>(b2) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE(x != y, SCREAM_EINVAL);  // the residual of a row is read twice, long after its neighbours were written
+    TailScales sc{1.f, 1.f, 1e-5f, 1.f, 1.f, 1.f, 1e-5f};
+    if (split == SCREAM_SPLIT_H2) SCREAM_REQUIRE(tail_scales(exps, &sc), SCREAM_EINVAL);
+    const int64_t tiles = M / SCREAM_ROW_TILE;
+    if (tiles == 0) return 0;
+    SCREAM_REQUIRE(tiles < (1ll << 31), SCREAM_EUNSUPPORTED);
+    const unsigned grid = tiles < T_MAX_GRID ? (unsigned)tiles : (unsigned)T_MAX_GRID;
+    if (split == SCREAM_SPLIT_H2)
+        tail_kernel<SplitH2><<<dim3(grid), dim3(TT), 0, as_stream(stream)>>>(Q, reinterpret_cast<const char*>(kv_image), tile_cloud,
+                                                                             kv_cloud_offset, cloud_len, x, reinterpret_cast<const char*>(tail_image),
+                                                                             g1, b1, g2, b2, y, (int)tiles, sc);
+    else
+        tail_kernel<SplitBf3><<<dim3(grid), dim3(TT), 0, as_stream(stream)>>>(Q, reinterpret_cast<const char*>(kv_image), tile_cloud,
+                                                                              kv_cloud_offset, cloud_len, x, reinterpret_cast<const char*>(tail_image),
+                                                                              g1, b1, g2, b2, y, (int)tiles, sc);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int scream_act_layout(const float* src, float* dst, int64_t M, int32_t to_fragment, void* stream) {
+    SCREAM_REQUIRE(src && dst && src != dst, SCREAM_EINVAL);
+    SCREAM_REQUIRE(M >= 0 && M % 32 == 0 && M / 32 < (1ll << 31), SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0, SCREAM_EINVAL);
+    if (M == 0) return 0;
+    act_layout_kernel<<<dim3((unsigned)(M / 32)), dim3(256), 0, as_stream(stream)>>>(src, dst, to_fragment ? 1 : 0);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}

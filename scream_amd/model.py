@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 from torch import nn
 
-from . import _lib, ops
+from . import _lib, ops, scales
 from .packing import PackedBatch
 
 D_MODEL = 256
@@ -89,23 +89,41 @@ class PointTransformer(nn.Module):
     def _stem_tgt_modules(self) -> Optional[List[_MHAParams]]:
         return None  # PointTransformer: one stem for both clouds
 
-    # GEMM path of the forward: "x3" = bf16 matrix cores with 3-way operand splitting (fp32-level accuracy, ~1.5x
-    # the throughput), "f32" = fp32-input MFMA.  Both are held to the same parity tolerances; SCREAM_GEMM overrides.
-    gemm_backend = os.environ.get("SCREAM_GEMM", "x3")
+    # GEMM path of the forward.  "h2" (default since round 3): fp16 matrix cores, operands split in two fp16 planes with
+    # power-of-two scales derived from the weights (scream_amd/scales.py), three products -- fp32-level accuracy at half the
+    # matrix instructions of "x3" (bf16 matrix cores, three planes, six products; scale invariant, rounds 1-2);
+    # "f32" = fp32-input MFMA.  All three are held to the same parity tolerances; SCREAM_GEMM overrides.
+    gemm_backend = os.environ.get("SCREAM_GEMM", "h2")
 
-    # x3 only: run FFN-up + relu + FFN-down + residual + LayerNorm2 as one launch (csrc/tail_x3.hip); SCREAM_FUSED_FFN=0
-    # keeps the two GEMM launches (same arithmetic, the hidden activations then go through HBM)
-    fused_ffn = os.environ.get("SCREAM_FUSED_FFN", "1") != "0"
-    # x3 only: attention apply, merge + LayerNorm1 and the FFN + LayerNorm2 as one launch per block; SCREAM_FUSED_TAIL=0
-    # falls back to attn_apply + merge GEMM + (fused or two-launch) FFN
+    # split backends only: attention apply, merge + LayerNorm1 and the FFN + LayerNorm2 as one launch per block
+    # (csrc/tail_split.hip); SCREAM_FUSED_TAIL=0 falls back to attn_apply + three GEMM launches (same arithmetic, the
+    # intermediate activations then go through HBM)
     fused_tail = os.environ.get("SCREAM_FUSED_TAIL", "1") != "0"
-    # fused tail only, OFF by default: the q/k/v projections on the ring-design kernel (csrc/proj_x3.hip) instead of the 8-wave
-    # split GEMM.  Same results to rounding; measured 0.6 % slower per step (its elu / split rides do not hide under the MFMAs of
-    # a lone wave).  SCREAM_RING_PROJ=1.
-    ring_proj = os.environ.get("SCREAM_RING_PROJ", "0") != "0"
 
     def _signature(self):
-        return (self.gemm_backend, self.fused_ffn, self.fused_tail, self.ring_proj) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.gemm_backend, self.fused_tail) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _layer_inputs(self):
+        """(in_q, in_kv) per layer of _layer_modules() [+ per layer of _stem_tgt_modules()] and the coordinate MLP's input:
+        the (gamma, beta) of the LayerNorm that produced each block input (models/pointnet.py:48-57) -- what bounds it."""
+        ln = lambda n: (n.weight, n.bias)
+        mods, tgt_mods = self._layer_modules(), self._stem_tgt_modules()
+        ns = self.self_layer_num
+        pre = ln(self.pre_norm)
+        ins, prev = [], pre
+        for i in range(ns):  # stem (on the source side for DEMTransformer)
+            ins.append((prev, prev))
+            prev = ln(mods[i].norm2)
+        src_in = prev
+        tgt_ins, prev_t = [], pre
+        for m in (tgt_mods or []):
+            tgt_ins.append((prev_t, prev_t))
+            prev_t = ln(m.norm2)
+        tgt_in = prev_t if tgt_mods else src_in  # the frozen target features of the cross stage
+        for j in range(2 * self.cross_layer_num):
+            ins.append((src_in, src_in if j % 2 == 0 else tgt_in))
+            src_in = ln(mods[ns + j].norm2)
+        return ins, tgt_ins, src_in
 
     def _pack_weights(self):
         sig = self._signature()
@@ -122,52 +140,44 @@ class PointTransformer(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
-        if self.gemm_backend not in ("x3", "f32"):
-            raise ValueError("gemm_backend must be 'x3' or 'f32', got %r" % (self.gemm_backend,))
-        planes = self.gemm_backend == "x3"
+        if self.gemm_backend not in ("h2", "x3", "f32"):
+            raise ValueError("gemm_backend must be 'h2', 'x3' or 'f32', got %r" % (self.gemm_backend,))
+        split = {"h2": _lib.SPLIT_H2, "x3": _lib.SPLIT_BF3, "f32": 0}[self.gemm_backend]
 
-        def dev_mat(t):  # a weight MATRIX: fp32 [N,K], or its three bf16 planes for the split GEMM
-            if not planes:
-                return dev_f32(t)
-            t = ops.split_planes(t.detach().to(device=dev, dtype=torch.float32))
-            keep.append(t)
-            return t.data_ptr()
+        def dev_mat(t):  # a weight MATRIX: fp32 [N,K], or its operand planes for the split GEMM; returns (pointer, exponent)
+            if not split:
+                return dev_f32(t), 0
+            pw = ops.pack_w(t.detach().to(device=dev, dtype=torch.float32), split)
+            keep.append(pw.data)
+            return pw.data_ptr(), pw.w_exp
 
         mods = self._layer_modules()
         tgt_mods = self._stem_tgt_modules() or []
+        ins, tgt_ins, coor_in = self._layer_inputs()
         layers = (_lib.LayerT * len(mods))()
         tgt_layers = (_lib.LayerT * max(len(tgt_mods), 1))()
-        for L, m in list(zip(layers, mods)) + list(zip(tgt_layers, tgt_mods)):
+        for L, m, (in_q, in_kv) in list(zip(layers, mods, ins)) + list(zip(tgt_layers, tgt_mods, tgt_ins)):
             # [q | k heads 0-3 | v heads 0-3 | k heads 4-7 | v heads 4-7]: a 256-wide GEMM tile then holds K and V of
             # four heads for the same tokens, which is what the fused K^T V epilogue needs (include/scream_hip.h)
             k, v = m.k_proj.weight, m.v_proj.weight
             wkv = torch.cat([k[:128], v[:128], k[128:], v[128:]], dim=0)
-            L.wqkv = dev_mat(torch.cat([m.q_proj.weight, wkv], dim=0))
-            L.wq = dev_mat(m.q_proj.weight)
-            L.wkv = dev_mat(wkv)
+            L.wqkv, L.e_wqkv = dev_mat(torch.cat([m.q_proj.weight, wkv], dim=0))
+            L.wq, L.e_wq = dev_mat(m.q_proj.weight)
+            L.wkv, L.e_wkv = dev_mat(wkv)
+            ex = scales.layer_exps(m, in_q, in_kv) if split == _lib.SPLIT_H2 else {}
+            L.e_xq, L.e_xkv = ex.get("e_xq", 0), ex.get("e_xkv", 0)
+            L.tail_exps = ops.tail_exps(**ex)
             L.tail = None
-            if planes and self.fused_tail:  # one launch for everything behind the projections (scream_layer_tail_x3_f32)
+            if split and self.fused_tail:  # one launch for everything behind the projections (scream_layer_tail_f32)
                 f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32)
-                img = ops.pack_tail(f32(m.merge.weight), f32(m.mlp[0].weight), f32(m.mlp[2].weight))
-                keep.append(img)
+                img = ops.pack_tail(f32(m.merge.weight), f32(m.mlp[0].weight), f32(m.mlp[2].weight), split, L.tail_exps)
+                keep.append(img.data)
                 L.tail = img.data_ptr()
-            L.proj = None
-            if L.tail is not None and self.ring_proj:
-                img = ops.pack_proj(m.q_proj.weight.to(dev), m.k_proj.weight.to(dev), m.v_proj.weight.to(dev))
-                keep.append(img)
-                L.proj = img.data_ptr()
-            L.wm = dev_mat(m.merge.weight)
-            if L.tail is not None:
-                L.ffn, L.w1, L.w2 = None, None, None
-            elif planes and self.fused_ffn:  # one launch for the FFN half (scream_ffn_x3_f32); w1 / w2 are then unused
-                img = ops.pack_ffn(m.mlp[0].weight.detach().to(device=dev, dtype=torch.float32),
-                                   m.mlp[2].weight.detach().to(device=dev, dtype=torch.float32))
-                keep.append(img)
-                L.ffn, L.w1, L.w2 = img.data_ptr(), None, None
-            else:
-                L.ffn = None
-                L.w1 = dev_mat(m.mlp[0].weight)
-                L.w2 = dev_mat(m.mlp[2].weight)
+                L.wm, L.w1, L.w2 = None, None, None
+            else:  # separate GEMMs: packed with the same exponents the bounds were derived with
+                L.wm, L.e_wm_g = dev_mat(m.merge.weight)
+                L.w1, L.e_w1_g = dev_mat(m.mlp[0].weight)
+                L.w2, L.e_w2_g = dev_mat(m.mlp[2].weight)
             L.g1, L.b1 = dev_f32(m.norm1.weight), dev_f32(m.norm1.bias)
             L.g2, L.b2 = dev_f32(m.norm2.weight), dev_f32(m.norm2.bias)
         mt = _lib.ModelT()
@@ -178,10 +188,15 @@ class PointTransformer(nn.Module):
         mt.pre_g, mt.pre_b = dev_f32(self.pre_norm.weight), dev_f32(self.pre_norm.bias)
         mt.layers_host = C.cast(layers, C.POINTER(_lib.LayerT))
         mt.stem_tgt_layers_host = C.cast(tgt_layers, C.POINTER(_lib.LayerT)) if tgt_mods else None
-        mt.gemm_planes = int(planes)
-        mt.c0_w, mt.c0_b = dev_mat(self.coor_mlp[0].weight[:, :, 0]), dev_f32(self.coor_mlp[0].bias)
-        mt.c2_w, mt.c2_b = dev_mat(self.coor_mlp[2].weight[:, :, 0]), dev_f32(self.coor_mlp[2].bias)
+        mt.gemm_split = split
+        c0w, c2w = self.coor_mlp[0].weight[:, :, 0], self.coor_mlp[2].weight[:, :, 0]
+        (mt.c0_w, mt.e_c0w), mt.c0_b = dev_mat(c0w), dev_f32(self.coor_mlp[0].bias)
+        (mt.c2_w, mt.e_c2w), mt.c2_b = dev_mat(c2w), dev_f32(self.coor_mlp[2].bias)
         mt.c4_w, mt.c4_b = dev_f32(self.coor_mlp[4].weight[:, :, 0]), dev_f32(self.coor_mlp[4].bias)
+        if split == _lib.SPLIT_H2:  # coor_mlp (models/pointnet.py:27-33): LayerNorm2 output -> Conv1d + bias, relu -> Conv1d
+            mt.e_c0x = scales.exp_for(scales.ln_bound(*coor_in))
+            mt.e_c2x = scales.exp_for(scales.lin_bound(c0w, *coor_in, bias=self.coor_mlp[0].bias))
+        self._fused = bool(split and self.fused_tail)
         self._packed = (mt, (layers, tgt_layers), keep)
         self._packed_sig = sig
         # the pack kernels and copies above were enqueued on the CURRENT stream; any other stream (a concurrent lane,
@@ -200,7 +215,7 @@ class PointTransformer(nn.Module):
         if ops._stream() not in self._packed_streams:  # first forward of this stream since the weights were packed
             torch.cuda.current_stream(dev).wait_event(self._packed_event)
             self._packed_streams.add(ops._stream())
-        need = lib.scream_forward_workspace_bytes(batch.rows_src, batch.rows_total, batch.n_pairs, batch.max_chunks)
+        need = lib.scream_forward_workspace_bytes(batch.rows_src, batch.rows_total, batch.n_pairs, batch.max_chunks, int(self._fused))
         # one scratch buffer per stream: concurrent lanes (scream_amd/lanes.py) run forwards of the same model side by side
         if self._ws is None:
             self._ws = {}

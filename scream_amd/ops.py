@@ -5,12 +5,15 @@ libscream_hip.so.  There is no CPU fallback: a tensor that is not on a HIP devic
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+from dataclasses import dataclass
 from typing import Optional, Tuple
 
 import torch
 
-from . import _lib
-from ._lib import check
+from . import _lib, scales
+from ._lib import SPLIT_BF3, SPLIT_H2, check
 
 EPI_NONE, EPI_ELU1, EPI_RELU, EPI_BIAS_RELU, EPI_RES_LN, EPI_QKV = 0, 1, 2, 3, 4, 5
 ROW_TILE = 128
@@ -52,14 +55,49 @@ def gemm_f32(A: torch.Tensor, W: torch.Tensor, epilogue: int = EPI_NONE, n_act: 
     return out
 
 
-def split_planes(W: torch.Tensor) -> torch.Tensor:
-    """[N,K] fp32 (on the GPU) -> the packed operand of the x3 GEMMs, [3, K/32, N, 32] bf16 (scream_pack_w_x3):
-    planes p0 + p1 + p2 == W exactly, re-tiled k-tile by k-tile in the kernel's LDS order."""
+@dataclass
+class PackedW:
+    """A weight matrix [N,K] in the split GEMM's operand image (scream_pack_w_split): `split` planes of 16-bit values,
+    [split, K/32, N, 32]; SPLIT_H2: of W * 2^w_exp."""
+    data: torch.Tensor
+    split: int
+    w_exp: int
+    N: int
+    K: int
+
+    def data_ptr(self) -> int:
+        return self.data.data_ptr()
+
+
+@dataclass
+class PackedTail:
+    """merge + mlp.0 + mlp.2 in the layer-tail kernel's 72-stage image (scream_pack_tail) with the exponents it was built for."""
+    data: torch.Tensor
+    split: int
+    exps: _lib.TailExpsT
+
+    def data_ptr(self) -> int:
+        return self.data.data_ptr()
+
+
+def default_split() -> int:
+    """The operand split behind gemm_backend: 'h2' (default) -> SPLIT_H2, 'x3' -> SPLIT_BF3."""
+    return SPLIT_BF3 if os.environ.get("SCREAM_GEMM", "h2") == "x3" else SPLIT_H2
+
+
+def pack_w(W: torch.Tensor, split: Optional[int] = None, w_exp: Optional[int] = None) -> PackedW:
+    """[N,K] fp32 (on the GPU) -> the packed operand of the split GEMMs (scream_pack_w_split).  SPLIT_BF3: planes
+    p0 + p1 + p2 == W exactly.  SPLIT_H2: two fp16 planes of W * 2^w_exp (default: the largest exponent max|W| allows)."""
+    split = default_split() if split is None else split
     W = W.detach().to(torch.float32).contiguous()
     N, K = W.shape
-    out = torch.empty(3, K // 32, N, 32, device=W.device, dtype=torch.bfloat16)
-    check(_lib.load().scream_pack_w_x3(_p(W), N, K, _p(out, torch.bfloat16), _stream()), "scream_pack_w_x3")
-    return out
+    if split == SPLIT_H2 and w_exp is None:
+        w_exp = scales.w_exp(W)
+    w_exp = int(w_exp or 0)
+    dt = torch.float16 if split == SPLIT_H2 else torch.bfloat16
+    out = torch.empty(split, K // 32, N, 32, device=W.device, dtype=dt)
+    check(_lib.load().scream_pack_w_split(_p(W), N, K, split, w_exp, _p(out, dt), _stream()), "scream_pack_w_split")
+    return PackedW(out, split, w_exp, N, K)
 
 
 LAYOUT_A_FRAG, LAYOUT_C_FRAG = 1, 2
@@ -74,55 +112,53 @@ def act_layout(X: torch.Tensor, to_fragment: bool) -> torch.Tensor:
     return out
 
 
-def gemm_x3(A: torch.Tensor, Wp: torch.Tensor, epilogue: int = EPI_NONE, n_act: int = 0,
-            bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-            gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
-            out: Optional[torch.Tensor] = None, layout: int = 0) -> torch.Tensor:
-    """gemm_f32's contract on the bf16 matrix cores (3-way split, fp32-level accuracy); Wp = split_planes(W).
+def _a_exp(A: torch.Tensor, Wp, a_exp: Optional[int]) -> int:
+    """SPLIT_H2 needs |A| 2^a_exp <= 2^15.  Callers that know a bound pass it; the convenience default measures max|A|
+    (a device synchronisation: tests and tools only -- the forward gets its exponents from the weights, scream_amd/scales.py)."""
+    if Wp.split != SPLIT_H2:
+        return 0
+    return scales.exp_for(A.abs().max().item()) if a_exp is None else int(a_exp)
+
+
+def gemm_split(A: torch.Tensor, Wp: PackedW, epilogue: int = EPI_NONE, n_act: int = 0,
+               bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+               gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None, layout: int = 0, a_exp: Optional[int] = None) -> torch.Tensor:
+    """gemm_f32's contract on the 16-bit matrix cores by operand splitting (fp32-level accuracy); Wp = pack_w(W).
     layout: LAYOUT_A_FRAG (A is fragment-major) | LAYOUT_C_FRAG (the activated query tile is written fragment-major)."""
     M, K = A.shape
-    N = Wp.shape[2]
-    assert Wp.shape == (3, K // 32, N, 32) and Wp.dtype == torch.bfloat16
+    assert K == Wp.K
     if out is None:
-        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
-    check(_lib.load().scream_gemm_x3_ex_f32(_p(A), A.stride(0), _p(Wp, torch.bfloat16), _p(out), out.stride(0), M, N, K,
+        out = torch.empty(M, Wp.N, device=A.device, dtype=torch.float32)
+    check(_lib.load().scream_gemm_split_f32(_p(A), A.stride(0), Wp.data_ptr(), _p(out), out.stride(0), M, Wp.N, K,
                                             epilogue, n_act, _p(bias), _p(residual),
                                             residual.stride(0) if residual is not None else 0, _p(gamma), _p(beta), layout,
-                                            _stream()),
-          "scream_gemm_x3_f32")
+                                            Wp.split, _a_exp(A, Wp, a_exp), Wp.w_exp, _stream()),
+          "scream_gemm_split_f32")
     return out
 
 
-def pack_ffn(W1: torch.Tensor, W2: torch.Tensor) -> torch.Tensor:
-    """mlp.0.weight [1024,256], mlp.2.weight [256,1024] (fp32, on the GPU) -> the weight image of ffn_x3 (uint8)."""
-    W1 = W1.detach().to(torch.float32).contiguous()
-    W2 = W2.detach().to(torch.float32).contiguous()
-    assert W1.shape == (4 * D_MODEL, D_MODEL) and W2.shape == (D_MODEL, 4 * D_MODEL)
-    lib = _lib.load()
-    out = torch.empty(lib.scream_ffn_image_bytes(), device=W1.device, dtype=torch.uint8)
-    check(lib.scream_pack_ffn_x3(_p(W1), _p(W2), _p(out, torch.uint8), _stream()), "scream_pack_ffn_x3")
-    return out
+def tail_exps(**kw) -> _lib.TailExpsT:
+    e = _lib.TailExpsT()
+    for k in ("e_att", "e_wm", "e_m1", "e_w1", "e_h", "e_w2"):
+        setattr(e, k, int(kw.get(k, 0)))
+    return e
 
 
-def ffn_x3(m1: torch.Tensor, image: torch.Tensor, residual: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """LayerNorm(residual + relu(m1 @ W1.T) @ W2.T) in one launch (scream_ffn_x3_f32); image = pack_ffn(W1, W2)."""
-    M = m1.shape[0]
-    if out is None:
-        out = torch.empty(M, D_MODEL, device=m1.device, dtype=torch.float32)
-    check(_lib.load().scream_ffn_x3_f32(_p(m1), m1.stride(0), _p(image, torch.uint8), _p(residual), residual.stride(0),
-                                        _p(gamma), _p(beta), _p(out), out.stride(0), M, _stream()), "scream_ffn_x3_f32")
-    return out
-
-
-def pack_tail(Wm: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor) -> torch.Tensor:
-    """merge.weight [256,256], mlp.0.weight [1024,256], mlp.2.weight [256,1024] -> the weight image of layer_tail."""
+def pack_tail(Wm: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, split: Optional[int] = None,
+              exps: Optional[_lib.TailExpsT] = None) -> PackedTail:
+    """merge.weight [256,256], mlp.0.weight [1024,256], mlp.2.weight [256,1024] -> the weight image of layer_tail.
+    SPLIT_H2 needs `exps` (scales.layer_exps / ops.tail_exps): the image carries e_wm, e_w1, e_w2, the kernel the rest."""
+    split = default_split() if split is None else split
     Wm, W1, W2 = (w.detach().to(torch.float32).contiguous() for w in (Wm, W1, W2))
     assert Wm.shape == (D_MODEL, D_MODEL) and W1.shape == (4 * D_MODEL, D_MODEL) and W2.shape == (D_MODEL, 4 * D_MODEL)
+    if split == SPLIT_H2 and exps is None:
+        raise ValueError("pack_tail(split=SPLIT_H2) needs the operand exponents (scream_amd/scales.py)")
+    exps = exps if exps is not None else tail_exps()
     lib = _lib.load()
-    out = torch.empty(lib.scream_tail_image_bytes(), device=Wm.device, dtype=torch.uint8)
-    check(lib.scream_pack_tail_x3(_p(Wm), _p(W1), _p(W2), _p(out, torch.uint8), _stream()), "scream_pack_tail_x3")
-    return out
+    out = torch.empty(lib.scream_tail_image_bytes(split), device=Wm.device, dtype=torch.uint8)
+    check(lib.scream_pack_tail(_p(Wm), _p(W1), _p(W2), split, C.byref(exps), _p(out, torch.uint8), _stream()), "scream_pack_tail")
+    return PackedTail(out, split, exps)
 
 
 def kv_finalize_x3(partial: torch.Tensor, cloud_row0, cloud_len, row_base: int, cloud_begin: int, n_kv: int,
@@ -137,61 +173,34 @@ def kv_finalize_x3(partial: torch.Tensor, cloud_row0, cloud_len, row_base: int, 
 
 
 def layer_tail(Q: torch.Tensor, kv_image: torch.Tensor, tile_cloud, kv_cloud_offset: int, cloud_len, x: torch.Tensor,
-               tail_image: torch.Tensor, g1, b1, g2, b2, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Attention apply + merge + norm1 + FFN + norm2 of one block in one launch (scream_layer_tail_x3_f32).
+               tail: PackedTail, g1, b1, g2, b2, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Attention apply + merge + norm1 + FFN + norm2 of one block in one launch (scream_layer_tail_f32).
     Q, x and the result are FRAGMENT-major [M,256] matrices (act_layout converts)."""
     M = Q.shape[0]
     assert Q.shape[1] == D_MODEL and x.shape == Q.shape
     if out is None:
         out = torch.empty(M, D_MODEL, device=Q.device, dtype=torch.float32)
-    check(_lib.load().scream_layer_tail_x3_f32(_p(Q), _p(kv_image, torch.uint8), _p(tile_cloud, torch.int32),
-                                               kv_cloud_offset, _p(cloud_len, torch.int32), _p(x),
-                                               _p(tail_image, torch.uint8), _p(g1), _p(b1), _p(g2), _p(b2), _p(out),
-                                               M, _stream()), "scream_layer_tail_x3_f32")
+    check(_lib.load().scream_layer_tail_f32(_p(Q), _p(kv_image, torch.uint8), _p(tile_cloud, torch.int32),
+                                            kv_cloud_offset, _p(cloud_len, torch.int32), _p(x),
+                                            tail.data_ptr(), _p(g1), _p(b1), _p(g2), _p(b2), _p(out),
+                                            M, tail.split, C.byref(tail.exps), _stream()), "scream_layer_tail_f32")
     return out
 
 
-def pack_proj(Wq: Optional[torch.Tensor], Wk: Optional[torch.Tensor], Wv: Optional[torch.Tensor]) -> torch.Tensor:
-    """q_proj / k_proj / v_proj .weight ([256,256] each; Wq or the pair Wk, Wv may be None) -> the weight image of proj_x3."""
-    ws = [None if w is None else w.detach().to(torch.float32).contiguous() for w in (Wq, Wk, Wv)]
-    assert all(w is None or w.shape == (D_MODEL, D_MODEL) for w in ws) and (ws[1] is None) == (ws[2] is None)
-    lib = _lib.load()
-    dev = next(w for w in ws if w is not None).device
-    out = torch.empty(lib.scream_proj_image_bytes(int(ws[0] is not None), int(ws[1] is not None)), device=dev, dtype=torch.uint8)
-    check(lib.scream_pack_proj_x3(*(None if w is None else _p(w) for w in ws), _p(out, torch.uint8), _stream()), "scream_pack_proj_x3")
-    return out
-
-
-def proj_x3(x: torch.Tensor, image: torch.Tensor, has_q: bool, has_kv: bool, tile_cloud=None, cloud_row0=None, cloud_len=None,
-            row_base: int = 0):
-    """q / k / v projections + fused K^T V on the ring-design kernel (scream_proj_x3_f32).  x and the returned Q' are
-    FRAGMENT-major [M,256]; image = pack_proj(...) (for has_kv only, of a full image: image[proj_image_bytes(1, 0):]).
-    Returns (Q' or None, kv_partial [M/128,8,1056] or None)."""
-    M = x.shape[0]
-    assert x.shape[1] == D_MODEL
-    Q = torch.empty(M, D_MODEL, device=x.device, dtype=torch.float32) if has_q else None
-    part = torch.empty(M // ROW_TILE, 8, KV_ELEMS, device=x.device, dtype=torch.float32) if has_kv else None
-    i32 = lambda t: None if t is None else _p(t, torch.int32)
-    check(_lib.load().scream_proj_x3_f32(_p(x), _p(image, torch.uint8), int(has_q), int(has_kv), None if Q is None else _p(Q),
-                                         None if part is None else _p(part), i32(tile_cloud), i32(cloud_row0), i32(cloud_len),
-                                         row_base, M, _stream()), "scream_proj_x3_f32")
-    return Q, part
-
-
-def gemm_qkv(A: torch.Tensor, W: torch.Tensor, n_q: int, tile_cloud, cloud_row0, cloud_len, row_base: int, layout: int = 0):
-    """Fused q/k/v projection (scream_gemm_qkv_f32).  Returns (Q' [M,256] or None, kv_partial [M/128,8,1056]).
-    layout (split kernel only): LAYOUT_A_FRAG | LAYOUT_C_FRAG."""
+def gemm_qkv(A: torch.Tensor, W, n_q: int, tile_cloud, cloud_row0, cloud_len, row_base: int, layout: int = 0,
+             a_exp: Optional[int] = None):
+    """Fused q/k/v projection (scream_gemm_qkv_f32 / scream_gemm_qkv_split_f32 for W = pack_w(...)).  Returns
+    (Q' [M,256] or None, kv_partial [M/128,8,1056]).  layout (split kernel only): LAYOUT_A_FRAG | LAYOUT_C_FRAG."""
     M, K = A.shape
-    N = W.shape[0]
-    x3 = W.dim() == 4  # packed bf16 planes (split_planes) -> the split kernel
-    if x3:
-        N = W.shape[2]
+    sp = isinstance(W, PackedW)  # packed operand planes -> the split kernel
+    N = W.N if sp else W.shape[0]
     Q = torch.empty(M, n_q, device=A.device, dtype=torch.float32) if n_q else None
     part = torch.empty(M // ROW_TILE, 8, KV_ELEMS, device=A.device, dtype=torch.float32)
-    args = (_p(A), A.stride(0), _p(W, torch.bfloat16 if x3 else torch.float32), _p(Q), n_q, M, N, K, n_q,
+    args = (_p(A), A.stride(0), W.data_ptr() if sp else _p(W), _p(Q), n_q, M, N, K, n_q,
             _p(tile_cloud, torch.int32), _p(cloud_row0, torch.int32), _p(cloud_len, torch.int32), row_base, _p(part))
-    if x3:
-        check(_lib.load().scream_gemm_qkv_x3_ex_f32(*args, layout, _stream()), "scream_gemm_qkv_x3")
+    if sp:
+        check(_lib.load().scream_gemm_qkv_split_f32(*args, layout, W.split, _a_exp(A, W, a_exp), W.w_exp, _stream()),
+              "scream_gemm_qkv_split_f32")
     else:
         assert layout == 0
         check(_lib.load().scream_gemm_qkv_f32(*args, _stream()), "scream_gemm_qkv")

@@ -1,0 +1,76 @@
+"""Power-of-two operand scales of the 2 x fp16 / 3-product split (csrc/split.h: SplitH2), derived from the WEIGHTS alone.
+
+fp16 has five exponent bits, so every operand of a SplitH2 product is multiplied by an exact 2^e before it is split, with
+the contract ``|x| * 2^e <= 2^15`` for every value the operand can take (fp16 overflows at 65 504; the factor two is the
+margin for fp32 rounding in the bounds below).  Nothing here looks at activations: the bounds are theorems about the
+network (models/transformer.py:74-90), so no input can overflow an operand and there is no run-time flag.
+
+  * a LayerNorm output  y = gamma * n + beta  has  sum n_j^2 = d var / (var + eps) <= d = 256, hence |n_j| <= 16:
+        |y_j| <= 16 |gamma_j| + |beta_j|                                        (block inputs x, the tail's m1)
+  * a bias-free Linear of a LayerNorm output, row w:  w . y = (w * gamma) . n + w . beta, and |n|_2 <= 16:
+        |w . y| <= 16 |w * gamma|_2 + |w . beta|                                 (q, k, v; the FFN's hidden units)
+  * the attention output of a row is a convex combination of value rows (the weights Q'.K' are non-negative, the 1e-6 in
+    the denominator only shrinks it; models/transformer.py:38-42):  |att_j| <= max |v_j| <= the bound on v;
+  * relu and elu + 1 do not increase a bound by more than 1.
+
+The bound fixes the exponent: e = floor(log2(2^15 / bound)), clamped.  Values below 2^-3 / 2^e lose relative precision
+(the second fp16 plane goes subnormal), i.e. operand values more than 2^18 below their bound -- 2^-40 of the operand's range
+in absolute terms.  Weight matrices take e from their largest |element|.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+TOP = 2.0 ** 15
+E_MIN, E_MAX = -24, 24  # keeps 2^(e_a + e_w) squared, times a variance, far inside fp32 (csrc/tail_split.hip: tail_scales)
+
+
+def exp_for(bound: float) -> int:
+    """Largest e with bound * 2^e <= 2^15 (clamped); bound = 0 or non-finite -> 0 / ValueError."""
+    b = float(bound)
+    if not math.isfinite(b):
+        raise ValueError("non-finite weights: no fp16 operand scale exists (use gemm_backend='x3')")
+    if b <= 0.0:
+        return E_MAX
+    return max(E_MIN, min(E_MAX, math.floor(math.log2(TOP / b))))
+
+
+def w_exp(W: torch.Tensor) -> int:
+    return exp_for(W.detach().double().abs().max().item())
+
+
+def ln_bound(gamma: torch.Tensor, beta: torch.Tensor) -> float:
+    """max_j |LayerNorm(.)_j|."""
+    return (16.0 * gamma.detach().double().abs() + beta.detach().double().abs()).max().item()
+
+
+def lin_bound(W: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Optional[torch.Tensor] = None) -> float:
+    """max_row |W[row] . LayerNorm(.)| (+ |bias|)."""
+    W, g, b = W.detach().double(), gamma.detach().double(), beta.detach().double()
+    out = 16.0 * (W * g).norm(dim=1) + (W @ b).abs()
+    if bias is not None:
+        out = out + bias.detach().double().abs()
+    return out.max().item()
+
+
+def tail_exps(Wm, W1, W2, g1, b1, v_bound: float) -> Dict[str, int]:
+    """Exponents of the layer tail (scream_tail_exps_t) from its weights and a bound on the value rows the attention mixes."""
+    e_att = exp_for(v_bound)
+    e_m1 = exp_for(ln_bound(g1, b1))
+    e_h = exp_for(lin_bound(W1, g1, b1))
+    e_wm, e_w1, e_w2 = w_exp(Wm), w_exp(W1), w_exp(W2)
+    # the accumulator units 2^(e_w + e_a) must stay within what the kernel's LayerNorm arithmetic was checked for
+    e_att = min(e_att, 40 - e_wm)
+    e_h = min(e_h, 40 - e_w2)
+    return {"e_att": e_att, "e_wm": e_wm, "e_m1": e_m1, "e_w1": e_w1, "e_h": e_h, "e_w2": e_w2}
+
+
+def layer_exps(m, in_q, in_kv) -> Dict[str, int]:
+    """Exponents of one MHAttention block.  m: parameter holder (q_proj, k_proj, v_proj, merge, mlp, norm1, norm2);
+    in_q / in_kv: (gamma, beta) of the LayerNorm that produced the query-side / key-value-side input."""
+    ex = tail_exps(m.merge.weight, m.mlp[0].weight, m.mlp[2].weight, m.norm1.weight, m.norm1.bias, lin_bound(m.v_proj.weight, *in_kv))
+    ex.update(e_xq=exp_for(ln_bound(*in_q)), e_xkv=exp_for(ln_bound(*in_kv)))
+    return ex

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import scream_ref as O
-from scream_amd import ops
+from scream_amd import ops, scales
 from scream_amd.synthetic import make_3dmatch_pair, make_state_dict
 
 pytestmark = pytest.mark.gpu
@@ -23,7 +23,8 @@ def dev(x):
     return torch.as_tensor(x).to(DEV)
 
 
-BACKENDS = ["x3", "f32"]  # both GEMM paths of the forward are held to the same tolerances
+BACKENDS = ["h2", "x3", "f32"]  # every GEMM path of the forward is held to the same tolerances
+SPLITS = {"h2": ops.SPLIT_H2, "x3": ops.SPLIT_BF3}  # 2 x fp16 / 3 products (default), 3 x bf16 / 6 products
 
 
 def build_net(seed, n_self, n_cross, backend=None):
@@ -37,11 +38,19 @@ def build_net(seed, n_self, n_cross, backend=None):
 
 # ------------------------------------------------------------------------------------- GEMM
 def _gemm(kind, A, W, *a, **k):
-    """The same GEMM contract on both matrix-core paths: fp32-input MFMA and 3 x bf16 split."""
-    return ops.gemm_f32(A, W, *a, **k) if kind == "f32" else ops.gemm_x3(A, ops.split_planes(W), *a, **k)
+    """The same GEMM contract on the three matrix-core paths: fp32-input MFMA, 3 x bf16 split, 2 x fp16 split (whose
+    operand exponents default to the largest that max|A|, max|W| allow -- what a caller with a bound would pass)."""
+    return ops.gemm_f32(A, W, *a, **k) if kind == "f32" else ops.gemm_split(A, ops.pack_w(W, SPLITS[kind]), *a, **k)
 
 
-@pytest.mark.parametrize("kind", ["f32", "x3"])
+def tail_exps_for(sd, pre, v_absmax):
+    """scream_tail_exps_t of block `pre` for inputs whose value rows stay below v_absmax (tests feed raw data, not LayerNorm
+    outputs, into single blocks: the forward derives the same exponents from the weights alone, scream_amd/scales.py)."""
+    return ops.tail_exps(**scales.tail_exps(sd[pre + "merge.weight"], sd[pre + "mlp.0.weight"], sd[pre + "mlp.2.weight"],
+                                            sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], v_absmax))
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
 @pytest.mark.parametrize("M,N,K", [(128, 256, 256), (384, 768, 256), (256, 1024, 256), (256, 256, 1024), (128, 512, 64), (66048, 256, 256)])
 def test_gemm_plain_and_activations(M, N, K, kind):
     g = torch.Generator().manual_seed(M + N + K)
@@ -62,15 +71,15 @@ def test_gemm_plain_and_activations(M, N, K, kind):
     torch.testing.assert_close(out.double(), (ref + bias.double()).clamp_min(0), rtol=1e-5, atol=2e-5)
 
 
-def test_pack_w_x3_is_an_exact_split():
-    """scream_pack_w_x3: the three bf16 planes sum back to W bit for bit (in fp32 and in fp64), and the image is the
+def test_pack_w_bf3_is_an_exact_split():
+    """scream_pack_w_split(SCREAM_SPLIT_BF3): the three bf16 planes sum back to W bit for bit (in fp32 and in fp64), and the image is the
     documented k-tile-major layout: logical chunk c = 2 half + s of a 32-deep k-slice holds the contraction indices
     8 (2 s + (j >> 2)) + 4 half + (j & 3), j = 0 .. 7 (what lane-half `half` supplies in step s), stored at chunk
-    c ^ ((n >> 2) & 3) (gemm_x3.hip)."""
+    c ^ ((n >> 2) & 3) (gemm_split.hip)."""
     g = torch.Generator().manual_seed(3)
     N, K = 512, 160
     W = torch.randn(N, K, generator=g) * torch.logspace(-6, 3, N).unsqueeze(1)  # nine decades of magnitudes
-    img = ops.split_planes(dev(W)).cpu()  # [3, K/32, N, 32]
+    img = ops.pack_w(dev(W), ops.SPLIT_BF3).data.cpu()  # [3, K/32, N, 32]
     assert img.shape == (3, K // 32, N, 32) and img.dtype == torch.bfloat16
     n = torch.arange(N)
     chunk = (torch.arange(4).view(1, 4) ^ ((n >> 2) & 3).view(N, 1))  # stored chunk cs of row n holds logical chunk cs ^ swz
@@ -92,32 +101,72 @@ def test_pack_w_x3_is_an_exact_split():
     assert torch.equal(planes[0], W.to(torch.bfloat16).float())
 
 
-def test_gemm_x3_rejects_unsupported_k():
+def test_pack_w_h2_planes_and_layout():
+    """scream_pack_w_split(SCREAM_SPLIT_H2): same k-tile-major layout with two fp16 planes of W * 2^w_exp: the leading plane
+    is the round-to-nearest fp16 of the scaled value, the second the fp16 of the exact residual, so the pair carries 22
+    significant bits; w_exp is the largest exponent that keeps max|W| 2^w_exp <= 2^15; elements more than 2^18 below the
+    largest one keep an ABSOLUTE accuracy of 2^-25 / 2^w_exp (fp16 subnormals are kept by the conversion and by the MFMA)."""
+    g = torch.Generator().manual_seed(3)
+    N, K = 512, 160
+    W = torch.randn(N, K, generator=g) * torch.logspace(-6, 3, N).unsqueeze(1)  # nine decades of magnitudes
+    pw = ops.pack_w(dev(W), ops.SPLIT_H2)
+    img = pw.data.cpu()
+    assert img.shape == (2, K // 32, N, 32) and img.dtype == torch.float16
+    s = 2.0 ** pw.w_exp
+    assert 2.0 ** 14 < float(W.abs().max()) * s <= 2.0 ** 15
+    n = torch.arange(N)
+    chunk = (torch.arange(4).view(1, 4) ^ ((n >> 2) & 3).view(N, 1))
+    planes = torch.empty(2, N, K, dtype=torch.float64)
+    for kt in range(K // 32):
+        rows = img[:, kt].double().view(2, N, 4, 8)
+        for cs in range(4):
+            c = chunk[:, cs]
+            for cc in range(4):
+                sel = c == cc
+                hf, st = cc >> 1, cc & 1
+                ks = [kt * 32 + 8 * (2 * st + (j >> 2)) + 4 * hf + (j & 3) for j in range(8)]
+                tmp = planes[:, sel]
+                tmp[:, :, ks] = rows[:, sel, cs]
+                planes[:, sel] = tmp
+    Ws = W.double() * s
+    assert torch.equal(planes[0], (W * s).to(torch.float16).double())
+    assert torch.equal(planes[1], ((W * s) - (W * s).to(torch.float16).float()).to(torch.float16).double())
+    err = (planes.sum(0) - Ws).abs()
+    assert bool((err <= Ws.abs() * 2.0 ** -22 + 2.0 ** -25).all())
+
+
+def test_gemm_split_rejects_unsupported_k_and_exponents():
     from scream_amd._lib import ScreamHipError
     A = torch.zeros(128, 128, device=DEV)
+    for split, dt in ((ops.SPLIT_BF3, torch.bfloat16), (ops.SPLIT_H2, torch.float16)):
+        with pytest.raises(ScreamHipError):
+            ops.pack_w(torch.zeros(256, 48, device=DEV), split, 0)  # K % 32
+        Wp = ops.PackedW(torch.zeros(split, 4, 256, 32, device=DEV, dtype=dt), split, 0, 256, 128)  # K = 128 is not 64 + 192 j
+        with pytest.raises(ScreamHipError):
+            ops.gemm_split(A, Wp, a_exp=0)
+        # K = 160: five k-tiles. 2 mod 3 but ODD -- the two-stage ring would read a stale stage (round-1 advisor finding)
+        with pytest.raises(ScreamHipError):
+            ops.gemm_split(torch.zeros(128, 160, device=DEV), ops.PackedW(torch.zeros(split, 5, 256, 32, device=DEV, dtype=dt), split, 0, 256, 160), a_exp=0)
     with pytest.raises(ScreamHipError):
-        ops.split_planes(torch.zeros(256, 48, device=DEV))  # K % 32
-    Wp = torch.zeros(3, 4, 256, 32, device=DEV, dtype=torch.bfloat16)  # K = 128 is not 64 + 192 j
+        ops.pack_w(torch.zeros(256, 256, device=DEV), 4, 0)  # no such split
+    W = ops.pack_w(torch.zeros(256, 256, device=DEV), ops.SPLIT_H2, 0)
     with pytest.raises(ScreamHipError):
-        ops.gemm_x3(A, Wp)
-    # K = 160: five k-tiles. 2 mod 3 but ODD -- the two-stage ring would read a stale stage (round-1 advisor finding)
-    with pytest.raises(ScreamHipError):
-        ops.gemm_x3(torch.zeros(128, 160, device=DEV), torch.zeros(3, 5, 256, 32, device=DEV, dtype=torch.bfloat16))
+        ops.gemm_split(torch.zeros(128, 256, device=DEV), W, a_exp=200)  # exponent outside the checked range
 
 
-@pytest.mark.parametrize("kind", ["f32", "x3"])
+@pytest.mark.parametrize("kind", BACKENDS)
 def test_gemm_asymmetric_identity(kind):
-    """A = I with an asymmetric W catches a transposed fragment/C map (cdna guide, section 3); exact on both paths
-    (the 3-way bf16 split of W is exact and 1.0 x w needs no rounding)."""
+    """A = I with an asymmetric W catches a transposed fragment/C map (cdna guide, section 3); exact on the fp32 and bf16 x 3
+    paths (the 3-way bf16 split of W is exact and 1.0 x w needs no rounding), to the 22 bits of its two planes on fp16 x 2."""
     K = N = 256
     A = torch.zeros(128, K)
     A[torch.arange(128), torch.arange(128)] = 1.0
     W = torch.arange(N * K, dtype=torch.float32).reshape(N, K) / 1000.0
     out = _gemm(kind, dev(A), dev(W)).cpu()
-    torch.testing.assert_close(out, W.t()[:128].contiguous(), rtol=0, atol=0)
+    torch.testing.assert_close(out, W.t()[:128].contiguous(), rtol=2.0 ** -22 if kind == "h2" else 0, atol=2.0 ** -25 if kind == "h2" else 0)
 
 
-@pytest.mark.parametrize("kind", ["f32", "x3"])
+@pytest.mark.parametrize("kind", BACKENDS)
 @pytest.mark.parametrize("K", [256, 1024])
 def test_gemm_residual_layernorm(K, kind):
     g = torch.Generator().manual_seed(K)
@@ -193,7 +242,7 @@ def test_kv_reduce_multichunk_vs_oracle():
     torch.testing.assert_close(kv[0, :, 32 * 32:], want["Ksum"][0], rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("kind", ["f32", "x3"])
+@pytest.mark.parametrize("kind", BACKENDS)
 def test_fused_qkv_projection_and_kv_reduce_vs_oracle(kind):
     """scream_gemm_qkv_f32 + scream_kv_finalize: Q' = elu(x Wq^T)+1 stored, K^T (V/S) and Ksum reduced from the
     accumulators per cloud -- against the oracle's intermediates, two ragged clouds incl. padding rows."""
@@ -211,7 +260,7 @@ def test_fused_qkv_projection_and_kv_reduce_vs_oracle(kind):
     W = torch.cat([q, k[:128], v[:128], k[128:], v[128:]], dim=0)
     tile_cloud = dev(torch.tensor([0, 0, 0, 1, 1], dtype=torch.int32))
     crow0, clen = dev(torch.tensor(row0, dtype=torch.int32)), dev(torch.tensor(lens, dtype=torch.int32))
-    pack = (lambda w: dev(w)) if kind == "f32" else (lambda w: ops.split_planes(dev(w)))
+    pack = (lambda w: dev(w)) if kind == "f32" else (lambda w: ops.pack_w(dev(w), SPLITS[kind]))
     Q, part = ops.gemm_qkv(dev(x), pack(W), 256, tile_cloud, crow0, clen, 0)
     kv = ops.kv_finalize(part, crow0, clen, 0, 0, 2, 2).cpu()
     for ci, (r0, xc) in enumerate(zip(row0, xs)):
@@ -229,88 +278,6 @@ def test_fused_qkv_projection_and_kv_reduce_vs_oracle(kind):
     torch.testing.assert_close(kv2[1], kv[1], rtol=0, atol=0)
 
 
-def test_ring_projection_kernel_vs_oracle_all_three_modes():
-    """scream_proj_x3_f32 (csrc/proj_x3.hip; fragment-major x in, fragment-major Q' out, K^T V partials) against the
-    oracle's intermediates in its three modes -- q|k|v (self layers), q only and k|v only with a row offset (cross layers)
-    -- on two ragged clouds with garbage in the padding rows; and against the 8-wave split GEMM it replaces."""
-    sd = make_state_dict(9, 256, 1, 1)
-    rng = np.random.default_rng(2)
-    lens, row0, rows = [300, 129], [0, 384], 640
-    x = torch.zeros(rows, 256)
-    xs = [torch.from_numpy(rng.normal(size=(n, 256)).astype(np.float32)) for n in lens]
-    for r0, xc in zip(row0, xs):
-        x[r0:r0 + xc.shape[0]] = xc
-    x[300:384] = 3.0  # garbage in padding rows must not reach the reduction
-    x[384 + 129:] = -7.0
-    q, k, v = (sd["stem.0.%s_proj.weight" % n] for n in "qkv")
-    tile_cloud = dev(torch.tensor([0, 0, 0, 1, 1], dtype=torch.int32))
-    crow0, clen = dev(torch.tensor(row0, dtype=torch.int32)), dev(torch.tensor(lens, dtype=torch.int32))
-    img = ops.pack_proj(dev(q), dev(k), dev(v))
-    from scream_amd import _lib
-    lib = _lib.load()
-    assert img.numel() == lib.scream_proj_image_bytes(1, 1) == 24 * 48 * 1024
-    xf = ops.act_layout(dev(x), True)
-    Qf, part = ops.proj_x3(xf, img, True, True, tile_cloud, crow0, clen, 0)
-    Q = ops.act_layout(Qf, False)
-    kv = ops.kv_finalize(part, crow0, clen, 0, 0, 2, 2).cpu()
-    for ci, (r0, xc) in enumerate(zip(row0, xs)):
-        want = {}
-        O.mh_attention(xc[None], xc[None], xc[None], sd, "stem.0.", want)
-        n = xc.shape[0]
-        torch.testing.assert_close(Q[r0:r0 + n].cpu().reshape(n, 8, 32), want["Q"][0], rtol=1e-5, atol=1e-5)
-        kvt = kv[ci, :, :1024].reshape(8, 32, 32)  # [h][v][d]
-        torch.testing.assert_close(kvt.permute(0, 2, 1), want["KV"][0], rtol=1e-4, atol=1e-5)
-        torch.testing.assert_close(kv[ci, :, 1024:], want["Ksum"][0], rtol=1e-5, atol=1e-4)
-    # the kernel it replaces: same numbers to fp32 rounding (other summation order inside K^T V)
-    W = torch.cat([q, k[:128], v[:128], k[128:], v[128:]], dim=0)
-    Qg, partg = ops.gemm_qkv(xf, ops.split_planes(dev(W)), 256, tile_cloud, crow0, clen, 0, ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG)
-    real = torch.zeros(rows, dtype=torch.bool)
-    for r0, n in zip(row0, lens):
-        real[r0:r0 + n] = True
-    torch.testing.assert_close(Q[real.to(DEV)], ops.act_layout(Qg, False)[real.to(DEV)], rtol=2e-6, atol=2e-6)
-    torch.testing.assert_close(part, partg, rtol=1e-5, atol=2e-4)
-    # q only: the first 8 stages of the same image, and an image packed from Wq alone
-    Q1, none = ops.proj_x3(xf, img, True, False)
-    assert none is None and torch.equal(Q1, Qf)
-    Q2, _ = ops.proj_x3(xf, ops.pack_proj(dev(q), None, None), True, False)
-    assert torch.equal(Q2, Qf)
-    # k|v only, rows offset by row_base (the cross layers' target side): bitwise the same partials as the full kernel's
-    off = lib.scream_proj_image_bytes(1, 0)
-    _, part2 = ops.proj_x3(xf[384:], img[off:], False, True, tile_cloud, crow0, clen, 384)
-    assert torch.equal(part2, part[3:])
-    _, part3 = ops.proj_x3(xf[384:], ops.pack_proj(None, dev(k), dev(v)), False, True, tile_cloud, crow0, clen, 384)
-    assert torch.equal(part3, part[3:])
-
-
-def test_ring_projection_kernel_many_tiles_per_block_bitwise_repeatable():
-    """More tiles than the 256 persistent blocks (tile loop, next-tile x requests, the exchange buffer's reuse across tiles):
-    333 312 rows in 65 clouds of odd lengths vs the split GEMM; the launch is bitwise repeatable and does not depend on the
-    number of tiles a block walks (the first rows of a longer launch equal a shorter launch of those rows)."""
-    g = torch.Generator(device=DEV).manual_seed(4)
-    M = 333312
-    n_tiles = M // 128
-    per = 40
-    n_clouds = (n_tiles + per - 1) // per
-    tile_cloud = (torch.arange(n_tiles, device=DEV) // per).int()
-    crow0 = (torch.arange(n_clouds, device=DEV) * per * 128).int()
-    clen = torch.full((n_clouds,), per * 128 - 77, device=DEV, dtype=torch.int32)
-    clen[-1] = M - int(crow0[-1]) - 5
-    x = torch.randn(M, 256, device=DEV, generator=g)
-    Wq, Wk, Wv = (torch.randn(256, 256, device=DEV, generator=g) / 16 for _ in range(3))
-    img = ops.pack_proj(Wq, Wk, Wv)
-    xf = ops.act_layout(x, True)
-    Qf, part = ops.proj_x3(xf, img, True, True, tile_cloud, crow0, clen, 0)
-    Qf2, part2 = ops.proj_x3(xf, img, True, True, tile_cloud, crow0, clen, 0)
-    assert torch.equal(Qf, Qf2) and torch.equal(part, part2)
-    W = torch.cat([Wq, Wk[:128], Wv[:128], Wk[128:], Wv[128:]], dim=0)
-    Qg, partg = ops.gemm_qkv(xf, ops.split_planes(W), 256, tile_cloud, crow0, clen, 0, ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG)
-    torch.testing.assert_close(Qf, Qg, rtol=5e-6, atol=5e-6)
-    torch.testing.assert_close(part, partg, rtol=1e-5, atol=1e-3)
-    rows = 40 * 128 * 3  # three whole clouds
-    Qs, ps = ops.proj_x3(xf[:rows], img, True, True, tile_cloud, crow0, clen, 0)
-    assert torch.equal(Qs, Qf[:rows]) and torch.equal(ps, part[:rows // 128])
-
-
 # ----------------------------------------------------------------- A1-A6 whole forward pass
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_forward_vs_reference_golden(golden, backend):
@@ -324,27 +291,23 @@ def test_forward_vs_reference_golden(golden, backend):
                                    err_msg="case seed=%d" % seed)
 
 
-@pytest.mark.parametrize("variant", ["ring_proj", "no_fused_tail", "no_fused_tail_no_fused_ffn"])
-def test_forward_every_split_path_variant_vs_reference_golden(golden, variant):
-    """The split-bf16 forward has one default path (8-wave projection GEMM + one-launch layer tail) and three selectable ones:
-    the ring-design projection kernel (SCREAM_RING_PROJ / net.ring_proj), the unfused tail (SCREAM_FUSED_TAIL=0: attention
-    apply + merge GEMM + one-launch FFN) and the fully unfused chain (also SCREAM_FUSED_FFN=0).  Same arithmetic, different
-    kernels and summation orders: each reproduces the reference's outputs to the default path's tolerance and agrees with the
-    default path to fp32 rounding."""
+@pytest.mark.parametrize("backend", ["h2", "x3"])
+def test_forward_unfused_tail_vs_reference_golden(golden, backend):
+    """Each split forward has one default path (projection GEMM with fused K^T V + one-launch layer tail) and one fallback:
+    the unfused tail (SCREAM_FUSED_TAIL=0 / net.fused_tail = False: attention apply + merge GEMM + FFN-up + FFN-down launches,
+    row-major activations, the 9 KB-per-row workspace).  Same arithmetic and operand exponents, different kernels and
+    summation orders: it reproduces the reference's outputs to the default path's tolerance and agrees with the default
+    path to fp32 rounding."""
     g = golden("e2e")
     for seed, ns, nc, n, m, explicit in g["cases"]:
         center = dev(g["center_%d" % seed]) if explicit else None
         outs = {}
-        for name in ("default", variant):
-            net = build_net(int(seed), int(ns), int(nc), "x3")
-            if name == "ring_proj":
-                net.ring_proj = True
-            elif name.startswith("no_fused_tail"):
-                net.fused_tail = False
-                net.fused_ffn = name == "no_fused_tail"
+        for name in ("default", "no_fused_tail"):
+            net = build_net(int(seed), int(ns), int(nc), backend)
+            net.fused_tail = name == "default"
             outs[name] = net(dev(g["src_%d" % seed]), dev(g["tgt_%d" % seed]), center, 1.0, False, False, None)[0]
-        np.testing.assert_allclose(outs[variant].cpu().numpy(), g["out_%d" % seed], rtol=2e-4, atol=5e-5, err_msg="case seed=%d" % seed)
-        torch.testing.assert_close(outs[variant], outs["default"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(outs["no_fused_tail"].cpu().numpy(), g["out_%d" % seed], rtol=2e-4, atol=5e-5, err_msg="case seed=%d" % seed)
+        torch.testing.assert_close(outs["no_fused_tail"], outs["default"], rtol=2e-5, atol=2e-5)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -549,9 +512,10 @@ def test_dem_transformer_vs_reference_golden(golden, backend):
         torch.testing.assert_close(chamfer_distance(dem_, dev(gt)).cpu(), want, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("split", ["h2", "x3"])
 @pytest.mark.parametrize("epi", ["relu", "res_ln", "qkv"])
-def test_gemm_x3_persistent_blocks_many_tiles(epi):
-    """Every block of the persistent x3 grid walks >= 3 output tiles (plus a ragged last round and a trailing 128-row
+def test_gemm_split_persistent_blocks_many_tiles(epi, split):
+    """Every block of the persistent split-GEMM grid walks >= 3 output tiles (plus a ragged last round and a trailing 128-row
     half tile): the counted waits across tile boundaries (next tile requested before the epilogue, its first barrier
     leaving the epilogue's stores in flight) must hold for every epilogue kind.  Checked against the fp32-MFMA kernel."""
     M = 256 * 256 * 3 + 37 * 256 + 128
@@ -559,14 +523,14 @@ def test_gemm_x3_persistent_blocks_many_tiles(epi):
     A = torch.randn(M, 256, device=DEV, generator=g)
     if epi == "relu":
         W = torch.randn(256, 256, device=DEV, generator=g) / 16
-        a = ops.gemm_x3(A, ops.split_planes(W), ops.EPI_RELU)
+        a = ops.gemm_split(A, ops.pack_w(W, SPLITS[split]), ops.EPI_RELU)
         b = ops.gemm_f32(A, W, ops.EPI_RELU)
         torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-5)
     elif epi == "res_ln":
         W = torch.randn(256, 256, device=DEV, generator=g) / 16
         res = torch.randn(M, 256, device=DEV, generator=g)
         gam, bet = torch.randn(256, device=DEV, generator=g), torch.randn(256, device=DEV, generator=g)
-        a = ops.gemm_x3(A, ops.split_planes(W), ops.EPI_RES_LN, residual=res, gamma=gam, beta=bet)
+        a = ops.gemm_split(A, ops.pack_w(W, SPLITS[split]), ops.EPI_RES_LN, residual=res, gamma=gam, beta=bet)
         b = ops.gemm_f32(A, W, ops.EPI_RES_LN, residual=res, gamma=gam, beta=bet)
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
     else:
@@ -577,14 +541,14 @@ def test_gemm_x3_persistent_blocks_many_tiles(epi):
         crow0 = (torch.arange(n_clouds, dtype=torch.int32, device=DEV) * 1024)
         clen = torch.full((n_clouds,), 1000, dtype=torch.int32, device=DEV)
         clen[-1] = min(1000, M - int(crow0[-1]))
-        qa, pa = ops.gemm_qkv(A, ops.split_planes(W), 256, tile_cloud, crow0, clen, 0)
+        qa, pa = ops.gemm_qkv(A, ops.pack_w(W, SPLITS[split]), 256, tile_cloud, crow0, clen, 0)
         qb, pb = ops.gemm_qkv(A, W, 256, tile_cloud, crow0, clen, 0)
         torch.testing.assert_close(qa, qb, rtol=1e-5, atol=2e-5)
         torch.testing.assert_close(pa, pb, rtol=1e-4, atol=2e-3)  # sums of 128 products of O(1) terms
 
 
-def test_gemm_x3_two_stream_soak_short():
-    """Six seconds of tools/x3_soak.py: random shapes and epilogues of the x3 GEMM against the fp32-MFMA GEMM on two
+def test_gemm_split_two_stream_soak_short():
+    """Six seconds of tools/x3_soak.py: random shapes and epilogues of the split GEMM (both splits) against the fp32-MFMA GEMM on two
     HIP streams at once (the lanes configuration).  The long form of this test is what caught a counted wait that was
     unsound across the epilogue's stores (once in ~10^5 launches); the short form guards against coarser mistakes."""
     import subprocess, sys, os
@@ -594,19 +558,53 @@ def test_gemm_x3_two_stream_soak_short():
 
 
 @pytest.mark.parametrize("shift", [40, -40, 100, -100])
-def test_gemm_x3_is_exactly_scale_invariant_at_full_size(shift):
-    """The split GEMM has no range caveat: bf16 keeps fp32's exponent, the three planes of 2^k * x are 2^k times the
+def test_gemm_bf3_is_exactly_scale_invariant_at_full_size(shift):
+    """The bf16 x 3 split GEMM has no range caveat: bf16 keeps fp32's exponent, the three planes of 2^k * x are 2^k times the
     planes of x, products and fp32 accumulation scale with them -- so gemm(2^k A) == 2^k gemm(A) BIT FOR BIT (as long
     as nothing leaves the normal fp32 range), here at the row count of the headline workload and |k| up to 100."""
     g = torch.Generator(device=DEV).manual_seed(5)
     M = 333184
     A = torch.randn(M, 256, device=DEV, generator=g)
     W = torch.randn(256, 256, device=DEV, generator=g) / 16
-    base = ops.gemm_x3(A, ops.split_planes(W))
+    base = ops.gemm_split(A, ops.pack_w(W, ops.SPLIT_BF3))
     half = shift // 2
-    scaled = ops.gemm_x3(A * (2.0 ** half), ops.split_planes(W * (2.0 ** (shift - half))))
+    scaled = ops.gemm_split(A * (2.0 ** half), ops.pack_w(W * (2.0 ** (shift - half)), ops.SPLIT_BF3))
     assert torch.equal(scaled * (2.0 ** -half) * (2.0 ** -(shift - half)), base)
     assert torch.isfinite(scaled).all()
+
+
+def test_gemm_h2_stated_operand_range():
+    """The fp16 x 2 split replaces scale INVARIANCE by a stated RANGE (split.h, include/scream_hip.h): with the exponent fixed
+    by a bound B on the operand (|a| 2^a_exp <= 2^15),
+      (1) a power of two moved between the data and its exponent changes nothing: gemm(2^k A; a_exp - k) == 2^k gemm(A; a_exp)
+          bit for bit, |k| <= 40, at the row count of the headline workload;
+      (2) data anywhere down to 2^-12 of the bound keep the full fp32-level accuracy of the split (<= 4e-7 normwise against
+          float64, the threshold of test_split_gemm_is_fp32_accurate_against_float64);
+      (3) below that the error is bounded in ABSOLUTE terms by the second plane's fp16 subnormal spacing: per product term
+          2^-25 / 2^a_exp = B 2^-40 -- rows 2^-20 and 2^-26 below the bound lose relative accuracy, never more than that."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    M = 333184
+    A = torch.randn(M, 256, device=DEV, generator=g)
+    W = torch.randn(256, 256, device=DEV, generator=g) / 16
+    Wp = ops.pack_w(W, ops.SPLIT_H2)
+    e = scales.exp_for(float(A.abs().max()))
+    base = ops.gemm_split(A, Wp, a_exp=e)
+    for k in (40, -40, 7):
+        moved = ops.gemm_split(A * (2.0 ** k), Wp, a_exp=e - k)
+        assert torch.equal(moved * (2.0 ** -k), base) and torch.isfinite(moved).all()
+    bound = 8.0  # as if a LayerNorm bound: a_exp = 12
+    a_exp = scales.exp_for(bound)
+    A1 = A[:4096].cpu()
+    W64, Wabs = W.cpu().double(), W.cpu().double().abs()
+    for j in (0, 4, 8, 12, 20, 26):
+        Aj = A1 * (bound / 8.0) * 2.0 ** -j  # largest values ~ B 2^-j / 2
+        out = ops.gemm_split(dev(Aj), Wp, a_exp=a_exp).cpu().double()
+        C64 = Aj.double() @ W64.t()
+        err = (out - C64).abs()
+        if j <= 12:
+            assert float((err / (Aj.double().abs() @ Wabs.t())).max()) <= 4e-7, j
+        # absolute: 256 terms, each off by at most |w| (2^-25 / 2^a_exp) from the subnormal plane, plus the fp32-level part
+        assert bool((err <= 256 * Wabs.max() * 2.0 ** -25 / 2.0 ** a_exp + 4e-7 * (Aj.double().abs() @ Wabs.t())).all()), j
 
 
 def test_nn_search_at_65536_points_finds_a_permuted_copy():
@@ -651,61 +649,12 @@ def test_kabsch_round_trip_at_65536_correspondences():
     assert float((back - torch.eye(4, dtype=torch.float64)).flatten(1).norm(dim=1).max()) < 1e-4
 
 
-# ------------------------------------------------------------------------------------- fused FFN (tail_x3.hip)
-def _ffn_reference(m1, W1, W2, x, g, b):
-    h = torch.relu(m1.double() @ W1.double().t())
-    return torch.nn.functional.layer_norm(x.double() + h @ W2.double().t(), (256,), g.double(), b.double(), 1e-5)
-
-
-@pytest.mark.parametrize("M", [128, 384, 33024])
-def test_fused_ffn_vs_float64_and_vs_two_launch_path(M):
-    """y = LayerNorm2(x + W2 relu(W1 m1)) in ONE launch (hidden activations stay in registers, transposed formulation
-    with permuted weight images) against float64, and against the two-GEMM path it replaces (same split-bf16
-    arithmetic, different summation order).  M = 33024 = 258 row tiles: persistent blocks walk several tiles and the
-    weight ring wraps across tile boundaries; asymmetric weights and row-dependent inputs catch any permutation slip."""
-    g_ = torch.Generator().manual_seed(M)
-    m1 = torch.randn(M, 256, generator=g_)
-    x = torch.randn(M, 256, generator=g_) * 2
-    W1 = torch.randn(1024, 256, generator=g_) / 16
-    W2 = torch.randn(256, 1024, generator=g_) / 32
-    g = torch.rand(256, generator=g_) + 0.5
-    b = torch.randn(256, generator=g_)
-    img = ops.pack_ffn(dev(W1), dev(W2))
-    out = ops.ffn_x3(dev(m1), img, dev(x), dev(g), dev(b)).cpu()
-    want = _ffn_reference(m1, W1, W2, x, g, b)
-    torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=2e-5)
-    hid = ops.gemm_x3(dev(m1), ops.split_planes(dev(W1)), ops.EPI_RELU)
-    two = ops.gemm_x3(hid, ops.split_planes(dev(W2)), ops.EPI_RES_LN, residual=dev(x), gamma=dev(g), beta=dev(b)).cpu()
-    err_fused, err_two = (out.double() - want).abs().max().item(), (two.double() - want).abs().max().item()
-    assert err_fused <= 2.0 * err_two + 1e-6, (err_fused, err_two)
-    # row-offset views (the forward hands in slices of its workspace): same result
-    big = torch.zeros(M + 256, 256, device=DEV)
-    big[128:128 + M] = dev(m1)
-    out2 = ops.ffn_x3(big[128:128 + M], img, dev(x), dev(g), dev(b))
-    assert torch.equal(out2.cpu(), out)
-
-
-def test_fused_ffn_identity_weights_expose_the_permutation():
-    """W1 = [I; 0] and W2 = [diag(1..256), 0]: y = LN(x + m1 * (1..256)) for m1 >= 0 -- every hidden unit and every
-    output feature carries a distinct tag, so a wrong row/column mapping in the packed images cannot cancel out."""
-    M = 128
-    m1 = torch.rand(M, 256) + torch.arange(M)[:, None] / M
-    x = torch.zeros(M, 256)
-    W1 = torch.zeros(1024, 256)
-    W1[:256] = torch.eye(256)
-    W2 = torch.zeros(256, 1024)
-    W2[:, :256] = torch.diag(torch.arange(1, 257, dtype=torch.float32))
-    g, b = torch.ones(256), torch.zeros(256)
-    out = ops.ffn_x3(dev(m1), ops.pack_ffn(dev(W1), dev(W2)), dev(x), dev(g), dev(b)).cpu()
-    want = _ffn_reference(m1, W1, W2, x, g, b)
-    torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=1e-5)
-
-
-# ------------------------------------------------------------------------------------- fused layer tail (tail_x3.hip)
+# ------------------------------------------------------------------------------------- fused layer tail (tail_split.hip)
+@pytest.mark.parametrize("split", ["h2", "x3"])
 @pytest.mark.parametrize("cross", [False, True])
-def test_fused_layer_tail_vs_oracle_block(cross):
+def test_fused_layer_tail_vs_oracle_block(cross, split):
     """One whole MHAttention block (models/transformer.py:74-90) on the fused path: q/k/v projection GEMM (K^T V in its
-    epilogue) -> scream_kv_finalize_x3 -> scream_layer_tail_x3_f32 (apply, merge + norm1, FFN + norm2 in ONE launch; att,
+    epilogue) -> scream_kv_finalize_x3 -> scream_layer_tail_f32 (apply, merge + norm1, FFN + norm2 in ONE launch; att,
     m1 and the hidden activations never reach memory) against the oracle block, on ragged clouds with padding rows, for
     a self block (three clouds, several row tiles per block) and a cross block (queries and keys from different clouds)."""
     sd = make_state_dict(21, 256, 1, 1)
@@ -723,15 +672,19 @@ def test_fused_layer_tail_vs_oracle_block(cross):
     crow0, clen = dev(torch.tensor(row0, dtype=torch.int32)), dev(torch.tensor(lens, dtype=torch.int32))
     q, k, v = (sd[pre + "%s_proj.weight" % n] for n in "qkv")
     Wkv = torch.cat([k[:128], v[:128], k[128:], v[128:]], dim=0)
-    img = ops.pack_tail(dev(sd[pre + "merge.weight"]), dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"]))
+    SPL = SPLITS[split]
+    pk = lambda w: ops.pack_w(dev(w), SPL)
+    v_absmax = float((x @ v.t()).abs().max()) * 1.01  # what bounds the attention output (scales.py derives it from the weights)
+    img = ops.pack_tail(dev(sd[pre + "merge.weight"]), dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"]), SPL,
+                        tail_exps_for(sd, pre, v_absmax))
     g1, b1, g2, b2 = (dev(sd[pre + n]) for n in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"))
     xd = dev(x)
     xf = ops.act_layout(xd, True)  # the fused path passes activations FRAGMENT-major between its kernels
     FR = ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG
     assert torch.equal(ops.act_layout(xf, False), xd)
     if not cross:
-        Q, part = ops.gemm_qkv(xf, ops.split_planes(dev(torch.cat([q, Wkv], dim=0))), 256, dev(tiles), crow0, clen, 0, FR)
-        Qr, part_r = ops.gemm_qkv(xd, ops.split_planes(dev(torch.cat([q, Wkv], dim=0))), 256, dev(tiles), crow0, clen, 0)
+        Q, part = ops.gemm_qkv(xf, pk(torch.cat([q, Wkv], dim=0)), 256, dev(tiles), crow0, clen, 0, FR)
+        Qr, part_r = ops.gemm_qkv(xd, pk(torch.cat([q, Wkv], dim=0)), 256, dev(tiles), crow0, clen, 0)
         assert torch.equal(ops.act_layout(Q, False), Qr) and torch.equal(part, part_r)  # same numbers, two layouts
         kvi = ops.kv_finalize_x3(part, crow0, clen, 0, 0, 3, 3)
         y = ops.act_layout(ops.layer_tail(Q, kvi, dev(tiles), 0, clen, xf, img, g1, b1, g2, b2), False).cpu()
@@ -740,8 +693,8 @@ def test_fused_layer_tail_vs_oracle_block(cross):
             torch.testing.assert_close(y[r0:r0 + xc.shape[0]], want, rtol=2e-4, atol=5e-5)
     else:
         # queries: cloud 0 (rows 0..383); keys/values: cloud 2 (rows 640..) -- "source attends to target", kv_cloud_offset 2
-        Q = ops.gemm_x3(xf[:384], ops.split_planes(dev(q)), ops.EPI_ELU1, n_act=256, layout=FR)
-        _, part = ops.gemm_qkv(xf[640:], ops.split_planes(dev(Wkv)), 0, dev(tiles), crow0, clen, 640, ops.LAYOUT_A_FRAG)
+        Q = ops.gemm_split(xf[:384], pk(q), ops.EPI_ELU1, n_act=256, layout=FR)
+        _, part = ops.gemm_qkv(xf[640:], pk(Wkv), 0, dev(tiles), crow0, clen, 640, ops.LAYOUT_A_FRAG)
         kvi = ops.kv_finalize_x3(part, crow0, clen, 640, 2, 1, 3)
         y = ops.act_layout(ops.layer_tail(Q, kvi, dev(tiles[:3].contiguous()), 2, clen, xf[:384], img, g1, b1, g2, b2), False).cpu()
         want = O.mh_attention(xs[0][None], xs[2][None], xs[2][None], sd, pre)[0]
@@ -749,10 +702,11 @@ def test_fused_layer_tail_vs_oracle_block(cross):
     assert torch.isfinite(y).all()
 
 
-def test_fused_layer_tail_many_tiles_equals_unfused_path():
+@pytest.mark.parametrize("split", ["h2", "x3"])
+def test_fused_layer_tail_many_tiles_equals_unfused_path(split):
     """33 024 rows = 258 row tiles on 256 persistent blocks (some blocks walk two tiles: the next tile's first two heads
     are applied under the current tile's last stages) in 40 ragged clouds: the fused tail against the kernels it
-    replaces (attn_apply + merge GEMM + fused FFN), same split-bf16 arithmetic, different summation order."""
+    replaces (attn_apply + merge GEMM + FFN-up + FFN-down), same split arithmetic and exponents, different summation order."""
     g_ = torch.Generator().manual_seed(3)
     n_clouds, rows = 40, 33024
     bounds = torch.linspace(0, rows // 128, n_clouds + 1).round().int()
@@ -771,16 +725,20 @@ def test_fused_layer_tail_many_tiles_equals_unfused_path():
     g1, b1, g2, b2 = (dev(sd[pre + n]) for n in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"))
     xd = dev(x)
     xf = ops.act_layout(xd, True)
-    Qf, part = ops.gemm_qkv(xf, ops.split_planes(dev(W)), 256, tc, crow0, clen, 0, ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG)
+    SPL = SPLITS[split]
+    pk = lambda w: ops.pack_w(dev(w), SPL)
+    Qf, part = ops.gemm_qkv(xf, pk(W), 256, tc, crow0, clen, 0, ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG)
     Q = ops.act_layout(Qf, False)
-    img = ops.pack_tail(dev(sd[pre + "merge.weight"]), dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"]))
+    ex = tail_exps_for(sd, pre, float((x @ v.t()).abs().max()) * 1.01)
+    img = ops.pack_tail(dev(sd[pre + "merge.weight"]), dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"]), SPL, ex)
     kvi = ops.kv_finalize_x3(part, crow0, clen, 0, 0, n_clouds, n_clouds)
     yf = ops.layer_tail(Qf, kvi, tc, 0, clen, xf, img, g1, b1, g2, b2)
     y = ops.act_layout(yf, False)
     kv = ops.kv_finalize(part, crow0, clen, 0, 0, n_clouds, n_clouds)
     att = ops.attn_apply(Q, 256, kv, tc, 0, clen, rows)
-    m1 = ops.gemm_x3(att, ops.split_planes(dev(sd[pre + "merge.weight"])), ops.EPI_RES_LN, residual=xd, gamma=g1, beta=b1)
-    want = ops.ffn_x3(m1, ops.pack_ffn(dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"])), xd, g2, b2)
+    m1 = ops.gemm_split(att, pk(sd[pre + "merge.weight"]), ops.EPI_RES_LN, residual=xd, gamma=g1, beta=b1, a_exp=ex.e_att)
+    hid = ops.gemm_split(m1, pk(sd[pre + "mlp.0.weight"]), ops.EPI_RELU, a_exp=ex.e_m1)
+    want = ops.gemm_split(hid, pk(sd[pre + "mlp.2.weight"]), ops.EPI_RES_LN, residual=xd, gamma=g2, beta=b2, a_exp=ex.e_h)
     valid = torch.zeros(rows, dtype=torch.bool)
     for r0, n in zip(row0, lens):
         valid[r0:r0 + n] = True

@@ -39,8 +39,13 @@ def test_library_exports_every_declared_symbol():
 
 def test_host_side_argument_checks_need_no_gpu():
     lib = _lib.load()
-    assert lib.scream_forward_workspace_bytes(128, 256, 1, 1) > 256 * (256 * 5 + 1024) * 4  # x0, x1, q, att, m1 + hidden
-    assert lib.scream_forward_workspace_bytes(256, 128, 1, 1) == -1  # rows_total < rows_src
+    unfused, fused = lib.scream_forward_workspace_bytes(128, 256, 1, 1, 0), lib.scream_forward_workspace_bytes(128, 256, 1, 1, 1)
+    assert unfused > 256 * (256 * 5 + 1024) * 4  # x0, x1, q, att, m1 + hidden
+    assert 256 * 256 * 3 * 4 < fused <= unfused - 256 * (256 * 2 + 1024) * 4  # the fused tail needs x0, x1, q only
+    assert lib.scream_forward_workspace_bytes(256, 128, 1, 1, 1) == -1  # rows_total < rows_src
+    # the split entry points validate `split` and the fp16 exponents on the host
+    assert lib.scream_tail_image_bytes(2) == 72 * 32 * 1024 and lib.scream_tail_image_bytes(3) == 72 * 48 * 1024
+    assert lib.scream_tail_image_bytes(4) == -1
     # NULL pointers / bad shapes are rejected before any launch
     assert lib.scream_gemm_f32(None, 256, None, None, 256, 128, 256, 256, 0, 0, None, None, 0, None, None, None) == -1
     assert lib.scream_nn_search(*([None] * 7), 1, 1, 1, 128, 128, 0.1, *([None] * 6)) == -1
@@ -313,20 +318,20 @@ def test_staging_buffers_alternate_and_grow():
     assert f3.numel() >= 5000                   # slot 1 regrown
 
 
-def test_x3_kernel_k_loop_has_no_register_spills(tmp_path):
-    """gemm_x3.hip loads its A operands with inline asm, so the compiler does not know those registers are in flight:
+def test_split_kernel_k_loop_has_no_register_spills(tmp_path):
+    """gemm_split.hip loads its A operands with inline asm, so the compiler does not know those registers are in flight:
     a spill (scratch store) of one of them inside the k-loop would save stale bytes.  Compile to assembly and require
     the k-loop of every instantiation to be free of scratch traffic (spills outside it only touch loop invariants)."""
     import re, shutil, subprocess
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not available")
-    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scream_amd", "csrc", "gemm_x3.hip")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scream_amd", "csrc", "gemm_split.hip")
     out = tmp_path / "x3.s"
     subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out), src],
                    check=True, capture_output=True, timeout=600)
     lines = out.read_text().splitlines()
-    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN.*gemm_x3_kernelILi\d+ELb[01]E.*:", l)]
-    assert len(starts) == 12  # six epilogues x two layouts of the A operand
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN.*gemm_split_kernelINS_\d+Split\w+ELi\d+ELb[01]E.*:", l)]
+    assert len(starts) == 24  # two operand splits x six epilogues x two layouts of the A operand
     checked = 0
     for a, b in zip(starts, starts[1:] + [len(lines)]):
         body = lines[a:b]
@@ -341,18 +346,19 @@ def test_x3_kernel_k_loop_has_no_register_spills(tmp_path):
 
         j = next(k for k in range(i, len(body)) if backward(k))
         loop = body[i:j]
-        assert sum("v_mfma_f32_32x32x16_bf16" in l for l in loop) == 288  # three k-tiles of 96 MFMAs
+        h2 = "SplitH2" in body[0]
+        assert sum(("v_mfma_f32_32x32x16_f16" if h2 else "v_mfma_f32_32x32x16_bf16") in l for l in loop) == (144 if h2 else 288)  # three k-tiles of 48 / 96 MFMAs
         assert not any("scratch_" in l for l in loop), "register spill inside the x3 k-loop"
         # the first operand registers of the NEXT tile are in flight during the epilogue as well: spill stores are only
         # tolerated in the kernel prologue, where they save loop invariants
         outer = next(k for k, l in enumerate(body) if "Loop Header: Depth=1" in l)
         assert not any("scratch_store" in l for l in body[outer:]), "spill store inside the persistent tile loop"
         checked += 1
-    assert checked == 12
+    assert checked == 24
 
 
 def test_no_instruction_touches_a_register_whose_asm_load_is_pending(tmp_path):
-    """gemm_x3.hip and tail_x3.hip load operands with inline asm and wait for them with hand-counted s_waitcnt vmcnt(N):
+    """gemm_split.hip and tail_split.hip load operands with inline asm and wait for them with hand-counted s_waitcnt vmcnt(N):
     hipcc believes such a register holds its value from the asm statement on and may copy, spill or reuse it before the
     wait (the round-1 advisor's finding; round 2 saw it happen -- a scratch_store of the destination right behind the
     load -- until the tail kernel stopped keeping requests pending across its LayerNorm blocks).
@@ -363,11 +369,8 @@ def test_no_instruction_touches_a_register_whose_asm_load_is_pending(tmp_path):
         pytest.skip("hipcc not available")
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import asm_inflight_check as chk
-    for src, extra, want in (("gemm_x3.hip", [], "gemm_x3_kernel"), ("tail_x3.hip", ["-ffp-contract=off"], "tail_x3_kernel"),
-                             ("proj_x3.hip", ["-ffp-contract=off"], "proj_x3_kernel"),
-                             # the 16x16x32 build option of the layer tail (SCREAM_TAIL_MFMA16=1): same guards, scratch allowed
-                             ("tail_x3.hip", ["-ffp-contract=off", "-DT_MFMA16=1"], "tail_x3_kernel")):
-        out = tmp_path / (src + ("16" if "-DT_MFMA16=1" in extra else "") + ".s")
+    for src, extra, want in (("gemm_split.hip", [], "gemm_split_kernel"), ("tail_split.hip", ["-ffp-contract=off"], "11tail_kernel")):  # (the mangled name: not pack_tail_kernel)
+        out = tmp_path / (src + ".s")
         subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-S", "--cuda-device-only", *extra, "-o", str(out),
                         os.path.join(REPO, "scream_amd", "csrc", src)], check=True, capture_output=True, timeout=900)
         n_kernels = 0
@@ -375,7 +378,7 @@ def test_no_instruction_touches_a_register_whose_asm_load_is_pending(tmp_path):
             if want not in name:
                 continue
             n_kernels += 1
-            n_loads = sum(1 for l in body if re.match(r"\s*global_load_dwordx4 [va]", l))  # (proj_x3 loads into AGPRs)
+            n_loads = sum(1 for l in body if re.match(r"\s*global_load_dwordx4 [va]", l))
             assert n_loads >= 16, (name, n_loads)  # the asm loads are there (the check is not vacuous)
             bad = chk.check_kernel(name, body)
             assert not bad, (name, bad[:5])
@@ -385,7 +388,7 @@ def test_no_instruction_touches_a_register_whose_asm_load_is_pending(tmp_path):
             # ... nor does a VALU instruction overwrite the data registers of a wide asm store right behind it (wrong dwords in
             # a quarter of the lanes, also round 2)
             assert not chk.check_store_data_hazard(name, body), name
-            if src in ("tail_x3.hip", "proj_x3.hip") and "-DT_MFMA16=1" not in extra:
+            if src == "tail_split.hip":
                 # The layer tail keeps NO scratch: a spilled value that is reloaded inside a stage puts a vmcnt(0) in front
                 # of its use (hipcc cannot order a scratch reload against the LDS-DMA in flight) and drains the weight ring
                 # once per stage -- it did, for a 64-bit per-lane pointer, until every address became scalar base + lane offset.
@@ -393,7 +396,7 @@ def test_no_instruction_touches_a_register_whose_asm_load_is_pending(tmp_path):
                 assert not any(re.match(r"\s*scratch_", l) for l in body), "scratch traffic in " + want
                 drains = sum(1 for l in body if re.match(r"\s*s_waitcnt vmcnt\(0\)", l))
                 assert drains <= 8, drains
-        assert n_kernels == {"gemm_x3.hip": 12, "tail_x3.hip": 1, "proj_x3.hip": 3}[src]
+        assert n_kernels == {"gemm_split.hip": 24, "tail_split.hip": 2}[src]  # both operand splits of each
 
 
 def test_the_static_checker_detects_what_it_is_there_for():
@@ -452,7 +455,7 @@ def test_f32_kernel_k_loop_has_no_register_spills(tmp_path):
     hipcc parks a handful of LOOP INVARIANTS (tile bookkeeping, epilogue pointers) in scratch: 6-18 dwords per
     instantiation, stored in the kernel prologue / at the top of the persistent tile loop and reloaded in the epilogue.
     That is harmless -- its A loads are ordinary compiler-tracked loads, so a spill can never capture an in-flight
-    register (unlike gemm_x3.hip's inline-asm loads) -- as long as none of it sits inside the k-loop, where it would cost
+    register (unlike gemm_split.hip's inline-asm loads) -- as long as none of it sits inside the k-loop, where it would cost
     a scratch round trip per 32-deep k-tile.  Pin exactly that."""
     import re, shutil, subprocess
     if shutil.which("hipcc") is None:

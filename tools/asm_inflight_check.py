@@ -187,6 +187,34 @@ def kernels(path):
         yield nm, lines[i:end]
 
 
+def verify_source(src, flags, out_s, want=""):
+    """Compile `src` to assembly with `flags` (the flags of the object that will run) and apply all three checks to every kernel
+    whose mangled name contains `want`; raises RuntimeError naming the first violation.  The ablation / stamp builds of the
+    tuning tools call this on EVERY variant before they produce a library: a -D switch that removes memory operations changes
+    what a hand-counted vmcnt(N) leaves in flight (round 2, gpurun_out/r2i: the "no weight DMA" variant of the layer tail was
+    launched with its ring waits still counting twelve pieces that no longer existed; the row operands were consumed while
+    pending, their registers recycled as per-lane 64-bit addresses, the loads landed in them, and the next access left the
+    aperture -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION)."""
+    import subprocess
+    r = subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-S", "--cuda-device-only", *flags, src, "-o", out_s],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc -S failed for %s:\n%s" % (src, r.stderr))
+    n = 0
+    for nm, body in kernels(out_s):
+        if want not in nm:
+            continue
+        n += 1
+        bad, hz, sd = check_kernel(nm, body), check_scalar_base_hazard(nm, body), check_store_data_hazard(nm, body)
+        if bad:
+            raise RuntimeError("%s %s: %s touches a register whose asm load is still in flight (%d places, first: %s)" % (src, flags, nm, len(bad), bad[0][1]))
+        if hz:
+            raise RuntimeError("%s %s: %s uses a scalar base %d wait states after a VALU write of it (%s -> %s)" % (src, flags, nm, hz[0][3], hz[0][2], hz[0][1]))
+        if sd:
+            raise RuntimeError("%s %s: %s overwrites the data of a wide store %d wait states behind it (%s ; %s)" % (src, flags, nm, sd[0][3], sd[0][1], sd[0][2]))
+    return n
+
+
 def main():
     path = sys.argv[1]
     want = sys.argv[2] if len(sys.argv) > 2 else ""

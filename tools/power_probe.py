@@ -7,7 +7,7 @@ from scream_amd import ops
 dev = "cuda:0"; M = 327680
 g = torch.Generator(device=dev).manual_seed(0)
 A = torch.randn(M, 256, device=dev, generator=g); W = torch.randn(1024, 256, device=dev, generator=g) / 16
-Wp = ops.split_planes(W); o = torch.empty(M, 1024, device=dev)
+Wp = ops.pack_w(W); o = torch.empty(M, 1024, device=dev)
 samples, stop = [], False
 def sampler():
     while not stop:
@@ -26,7 +26,7 @@ def burn(fn, secs, tag):
     dt = time.time() - t0
     print("%s: %.3f ms per launch, %.1f TFLOP/s, window [%.2f, %.2f]" % (tag, dt / n * 1e3, 2.0 * M * 1024 * 256 * n / dt / 1e12, t0, t0 + dt), flush=True)
 time.sleep(1.0)
-burn(lambda: ops.gemm_x3(A, Wp, ops.EPI_RELU, out=o), 4.0, "x3  FFN 256->1024")
+burn(lambda: ops.gemm_split(A, Wp, ops.EPI_RELU, out=o), 4.0, "x3  FFN 256->1024")
 time.sleep(1.0)
 burn(lambda: ops.gemm_f32(A, W, ops.EPI_RELU, out=o), 4.0, "f32 FFN 256->1024")
 time.sleep(1.0)

@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
-"""Soak test of the fused layer tail (tail_x3.hip: hand-counted vector-memory waits, a ring of LDS-DMA stages, operands
-requested a stage ahead): random row counts and cloud partitions on two streams at once for a fixed wall time.  Every
-draw is checked against the unfused chain (attention apply + merge GEMM + fused FFN: same arithmetic, other summation
-order) to a tolerance, and run twice -- the two runs must agree bit for bit.  usage: tail_soak.py [seconds] [seed]"""
+"""Soak test of the fused layer tail (tail_split.hip: hand-counted vector-memory waits, a ring of LDS-DMA stages, operands
+requested a stage ahead), a random one of its two operand splits per draw: random row counts and cloud partitions on two
+streams at once for a fixed wall time.  Every draw is checked against the unfused chain (attention apply + merge GEMM +
+FFN-up + FFN-down: same arithmetic and exponents, other summation order) to a tolerance, and run twice -- the two runs must
+agree bit for bit.  usage: tail_soak.py [seconds] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from scream_amd import ops
+from scream_amd import ops, scales
 dev = "cuda:0"; secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0); g = torch.Generator(device=dev).manual_seed(0)
 Wqkv = torch.randn(768, 256, device=dev, generator=g) / 16; Wm = torch.randn(256, 256, device=dev, generator=g) / 16
 W1 = torch.randn(1024, 256, device=dev, generator=g) / 16; W2 = torch.randn(256, 1024, device=dev, generator=g) / 32
 g1, b1, g2, b2 = (torch.randn(256, device=dev, generator=g) for _ in range(4))
-pq, pm, img, fimg = ops.split_planes(Wqkv), ops.split_planes(Wm), ops.pack_tail(Wm, W1, W2), ops.pack_ffn(W1, W2)
+XMAX = 6.0  # the block inputs below are clamped to it, which bounds every operand without looking at the data
+A_EXP = scales.exp_for(XMAX)
+Wv = torch.cat([Wqkv[384:512], Wqkv[640:768]])  # the value rows of [q | k0-3 | v0-3 | k4-7 | v4-7]
+EX = ops.tail_exps(**scales.tail_exps(Wm, W1, W2, g1, b1, XMAX * float(Wv.abs().sum(dim=1).max())))
+P = {sp: dict(q=ops.pack_w(Wqkv, sp), m=ops.pack_w(Wm, sp), w1=ops.pack_w(W1, sp), w2=ops.pack_w(W2, sp), img=ops.pack_tail(Wm, W1, W2, sp, EX))
+     for sp in (ops.SPLIT_H2, ops.SPLIT_BF3)}
 FR = ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG
 torch.cuda.synchronize()
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
@@ -30,16 +36,19 @@ while time.time() - t0 < secs:
         M = n_tiles * 128
         with torch.cuda.stream(st):
             tc, cr, cl = torch.from_numpy(tiles).to(dev), torch.from_numpy(row0).to(dev), torch.from_numpy(lens).to(dev)
-            x = torch.randn(M, 256, device=dev)
+            x = torch.randn(M, 256, device=dev).clamp_(-XMAX, XMAX)
             xf = ops.act_layout(x, True)
-            Qf, part = ops.gemm_qkv(xf, pq, 256, tc, cr, cl, 0, FR)
+            p = P[(ops.SPLIT_H2, ops.SPLIT_BF3)[rng.integers(2)]]
+            img = p["img"]
+            Qf, part = ops.gemm_qkv(xf, p["q"], 256, tc, cr, cl, 0, FR, a_exp=A_EXP)
             kvi = ops.kv_finalize_x3(part, cr, cl, 0, 0, n_clouds, n_clouds)
             y1 = ops.layer_tail(Qf, kvi, tc, 0, cl, xf, img, g1, b1, g2, b2)
             y2 = ops.layer_tail(Qf, kvi, tc, 0, cl, xf, img, g1, b1, g2, b2)
             kv = ops.kv_finalize(part, cr, cl, 0, 0, n_clouds, n_clouds)
             att = ops.attn_apply(ops.act_layout(Qf, False), 256, kv, tc, 0, cl, M)
-            m1 = ops.gemm_x3(att, pm, ops.EPI_RES_LN, residual=x, gamma=g1, beta=b1)
-            ref = ops.ffn_x3(m1, fimg, x, g2, b2)
+            m1 = ops.gemm_split(att, p["m"], ops.EPI_RES_LN, residual=x, gamma=g1, beta=b1, a_exp=EX.e_att)
+            hid = ops.gemm_split(m1, p["w1"], ops.EPI_RELU, a_exp=EX.e_m1)
+            ref = ops.gemm_split(hid, p["w2"], ops.EPI_RES_LN, residual=x, gamma=g2, beta=b2, a_exp=EX.e_h)
             yr = ops.act_layout(y1, False)
             valid = torch.zeros(M, dtype=torch.bool, device=dev)
             for r0, ln in zip(row0.tolist(), lens.tolist()):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Cycles per stage of tail_x3_kernel from in-kernel s_memtime stamps (diagnostic build with -DT_STAMPS; the shipped
-library has none).  `build` on the CPU box, `run` on the GPU: stamps of the second tile of every block, median over
+"""Cycles per stage of tail_kernel (T_SPLIT=h2 default / x3) from in-kernel s_memtime stamps (diagnostic build with -DT_STAMPS,
+verified by tools/asm_inflight_check.py before it is linked; the shipped library has none).  `build` on the CPU box, `run` on the GPU: stamps of the second tile of every block, median over
 blocks and waves, after a second of back-to-back launches so that the clock has settled."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,19 +8,25 @@ SO = os.path.join(ROOT, "tools", "_tabl", "t_stamps%s.so" % os.environ.get("T_TA
 
 
 def build():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import asm_inflight_check as chk
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-DT_STAMPS",
-                           *os.environ.get("T_EXTRA", "").split(), os.path.join(ROOT, "scream_amd/csrc/tail_x3.hip"), "-o", SO])
+    src = os.path.join(ROOT, "scream_amd/csrc/tail_split.hip")
+    flags = ["-ffp-contract=off", "-DT_STAMPS", *os.environ.get("T_EXTRA", "").split()]
+    assert chk.verify_source(src, flags, SO[:-3] + ".s", "11tail_kernel") == 2  # raises if a stamp pushed a pending register around
+    subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", *flags, src, "-o", SO])
 
 
 def run():
     sys.path.insert(0, ROOT)
     import numpy as np, torch
-    from scream_amd import ops
+    from scream_amd import _lib, ops, scales
     dev = "cuda:0"
     M = int(os.environ.get("T_M", 333312))
+    split = {"h2": ops.SPLIT_H2, "x3": ops.SPLIT_BF3}[os.environ.get("T_SPLIT", "h2")]
     g = torch.Generator(device=dev).manual_seed(0)
-    x = torch.randn(M, 256, device=dev, generator=g)
+    XMAX = 6.0
+    x = torch.randn(M, 256, device=dev, generator=g).clamp_(-XMAX, XMAX)
     W1 = torch.randn(1024, 256, device=dev, generator=g) / 16; W2 = torch.randn(256, 1024, device=dev, generator=g) / 32
     Wm = torch.randn(256, 256, device=dev, generator=g) / 16; Wqkv = torch.randn(768, 256, device=dev, generator=g) / 16
     gam, bet = torch.ones(256, device=dev), torch.zeros(256, device=dev)
@@ -29,20 +35,24 @@ def run():
     crow0 = (torch.arange(n_clouds, device=dev) * tpc * 128).int()
     clen = torch.full((n_clouds,), tpc * 128 - 17, device=dev, dtype=torch.int32); clen[-1] = M - int(crow0[-1]) - 5
     xf = ops.act_layout(x, True)
-    Qf, part = ops.gemm_qkv(xf, ops.split_planes(Wqkv), 256, tile_cloud, crow0, clen, 0, 3)
+    Qf, part = ops.gemm_qkv(xf, ops.pack_w(Wqkv, split), 256, tile_cloud, crow0, clen, 0, 3, a_exp=scales.exp_for(XMAX))
+    Wv = torch.cat([Wqkv[384:512], Wqkv[640:768]])
+    EX = ops.tail_exps(**scales.tail_exps(Wm, W1, W2, gam, bet, XMAX * float(Wv.abs().sum(dim=1).max())))
     lib = ctypes.CDLL(SO)
     V, I64, I32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
-    ft = lib.scream_layer_tail_x3_f32; ft.restype = ctypes.c_int; ft.argtypes = [V, V, V, I32, V, V, V, V, V, V, V, V, I64, V]
-    pt = lib.scream_pack_tail_x3; pt.restype = ctypes.c_int; pt.argtypes = [V, V, V, V, V]
+    ft = lib.scream_layer_tail_f32; ft.restype = ctypes.c_int
+    ft.argtypes = [V, V, V, I32, V, V, V, V, V, V, V, V, I64, I32, ctypes.POINTER(_lib.TailExpsT), V]
+    pt = lib.scream_pack_tail; pt.restype = ctypes.c_int; pt.argtypes = [V, V, V, I32, ctypes.POINTER(_lib.TailExpsT), V, V]
     kf = lib.scream_kv_finalize_x3; kf.restype = ctypes.c_int; kf.argtypes = [V, V, V, I64, I32, I32, V, V]
+    tb = lib.scream_tail_image_bytes; tb.restype = ctypes.c_int64; tb.argtypes = [I32]
     st = torch.cuda.current_stream().cuda_stream
-    timg = torch.empty(lib.scream_tail_image_bytes(), device=dev, dtype=torch.uint8)
-    assert pt(Wm.data_ptr(), W1.data_ptr(), W2.data_ptr(), timg.data_ptr(), st) == 0
+    timg = torch.empty(tb(split), device=dev, dtype=torch.uint8)
+    assert pt(Wm.data_ptr(), W1.data_ptr(), W2.data_ptr(), split, ctypes.byref(EX), timg.data_ptr(), st) == 0
     kvi = torch.zeros(n_clouds, lib.scream_kv_image_bytes(), device=dev, dtype=torch.uint8)
     assert kf(part.data_ptr(), crow0.data_ptr(), clen.data_ptr(), 0, 0, n_clouds, kvi.data_ptr(), st) == 0
     y = torch.empty(M, 256, device=dev)
     call = lambda: ft(Qf.data_ptr(), kvi.data_ptr(), tile_cloud.data_ptr(), 0, clen.data_ptr(), xf.data_ptr(), timg.data_ptr(), gam.data_ptr(),
-                      bet.data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(), M, st)
+                      bet.data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(), M, split, ctypes.byref(EX), st)
     import time
     t0 = time.time()
     while time.time() - t0 < 1.5:
@@ -55,10 +65,11 @@ def run():
     a = a[a[:, 5] > 0]
     d = np.diff(a[:, :6], axis=1)
     med = np.median(d, axis=0)
-    names = ["merge phase (8 stages, apply rides; floor 8 x 3456)", "norm1 + split into planes", "FFN phase (64 stages; floor 64 x 3072)",
-             "drain + open apply of the next tile's head 1", "norm2 + y stores"]
+    per_stage = 16 * (3 if split == ops.SPLIT_H2 else 6) * 32  # MFMA cycles of a stage
+    names = ["merge phase (8 stages, apply rides; floor 8 x %d)" % (per_stage + 384), "norm1 + split into planes",
+             "FFN phase (64 stages; floor 64 x %d)" % per_stage, "drain + open apply of the next tile's head 1", "norm2 + y stores"]
     tot = np.median(a[:, 5] - a[:, 0])
-    print("waves with stamps: %d; tile total median %d cycles (MFMA floor 72 x 3072 + 8 x 384 = 224256)" % (a.shape[0], tot))
+    print("waves with stamps: %d; tile total median %d cycles (MFMA floor 72 x %d + 8 x 384 = %d)" % (a.shape[0], tot, per_stage, 72 * per_stage + 8 * 384))
     for nm, v in zip(names, med):
         print("  %-58s %8d  %5.1f %%" % (nm, v, 100.0 * v / tot))
     # stage tops inside the merge phase (low 32 bits of s_memtime, kept in scalar registers until the tile's end)

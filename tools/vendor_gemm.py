@@ -8,7 +8,7 @@ dev = "cuda:0"; M = 327680
 g = torch.Generator(device=dev).manual_seed(0)
 for name, N, K in [("qkv", 768, 256), ("ffn1", 1024, 256), ("ffn2", 256, 1024), ("merge", 256, 256)]:
     A = torch.randn(M, K, device=dev, generator=g); W = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
-    Wt = W.t().contiguous(); Wp = ops.split_planes(W); o = torch.empty(M, N, device=dev)
+    Wt = W.t().contiguous(); Wp = ops.pack_w(W); o = torch.empty(M, N, device=dev)
     def t(fn):
         fn(); torch.cuda.synchronize(); ts = []
         for _ in range(5):
@@ -17,7 +17,7 @@ for name, N, K in [("qkv", 768, 256), ("ffn1", 1024, 256), ("ffn2", 256, 1024), 
             for _ in range(5): fn()
             e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 5)
         return sorted(ts)[2]
-    tv = t(lambda: torch.matmul(A, Wt, out=o)); t3 = t(lambda: ops.gemm_x3(A, Wp, out=o)); tf = t(lambda: ops.gemm_f32(A, W, out=o))
+    tv = t(lambda: torch.matmul(A, Wt, out=o)); t3 = t(lambda: ops.gemm_split(A, Wp, out=o)); tf = t(lambda: ops.gemm_f32(A, W, out=o))
     f = 2.0 * M * N * K / 1e9
     print("%-6s N=%4d K=%4d  vendor fp32 %.3f ms %.1f TF | gemm_x3 %.3f ms %.1f TF | gemm_f32 %.3f ms %.1f TF" % (name, N, K, tv, f / tv, t3, f / t3, tf, f / tf))
 

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Ablation timing of gemm_x3_kernel: builds scream_amd/csrc/gemm_x3.hip with -DX3_ABLATE=<bits> into tools/_abl/
-(`build`, on the CPU box) and times each variant on the forward's four GEMM shapes (`run`, on the GPU)."""
+"""Ablation timing of gemm_split_kernel (X3_SPLIT=h2 default | x3): builds scream_amd/csrc/gemm_split.hip with
+-DX3_ABLATE=<bits> into tools/_abl/ (`build`, on the CPU box; every variant passes tools/asm_inflight_check.py first or is
+skipped) and times each variant on the forward's four GEMM shapes (`run`, on the GPU)."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _split_ctypes as SC
 OUT = os.path.join(ROOT, "tools", "_abl" + os.environ.get("X3_TAG", ""))
 VARIANTS = [(0, "full")] if os.environ.get("X3_ONLY_FULL") else [(0, "full"), (64, "no epilogue stores"), (1, "no epilogue"), (1 | 2, "no epilogue, no W DMA"), (1 | 4, "no epilogue, no A loads"),
             (1 | 32, "no epilogue, no split"), (1 | 16, "no epilogue, no LDS reads"), (1 | 8, "no epilogue, no MFMA"),
@@ -12,11 +15,19 @@ if os.environ.get("X3_VARIANTS"):  # e.g. X3_VARIANTS=0,1 -> only those ablation
 EXTRA = os.environ.get("X3_EXTRA", "").split()
 
 def build():
+    import asm_inflight_check as chk
     os.makedirs(OUT, exist_ok=True)
     procs = []
-    for bits, _ in VARIANTS:
-        cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-DX3_ABLATE=%d" % bits, *EXTRA,
-               os.path.join(ROOT, os.environ.get("X3_SRC", "scream_amd/csrc/gemm_x3.hip")), "-o", os.path.join(OUT, "x3_%d.so" % bits)]
+    src = os.path.join(ROOT, os.environ.get("X3_SRC", SC.SRC))
+    for bits, label in VARIANTS:
+        flags = ["-DX3_ABLATE=%d" % bits, *EXTRA]
+        try:  # a switch that removes memory operations changes what the counted waits leave in flight: never launch unverified code
+            assert chk.verify_source(src, flags, os.path.join(OUT, "x3_%d.s" % bits), SC.KERNEL) == 12
+        except RuntimeError as e:
+            print("SKIPPED variant %d (%s): %s" % (bits, label, e), flush=True)
+            if os.path.exists(os.path.join(OUT, "x3_%d.so" % bits)): os.remove(os.path.join(OUT, "x3_%d.so" % bits))
+            continue
+        cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", *flags, src, "-o", os.path.join(OUT, "x3_%d.so" % bits)]
         procs.append(subprocess.Popen(cmd))
         if len(procs) == 4:
             for p in procs: assert p.wait() == 0
@@ -42,26 +53,18 @@ def run():
             f = os.path.join(d, "x3_%d.so" % bits)
             if not os.path.exists(f):
                 continue
-            lib = ctypes.CDLL(f)
-            fn = lib.scream_gemm_x3_f32
-            fn.restype = ctypes.c_int
-            fn.argtypes = [V, I64, V, V, I64, I64, I32, I32, I32, I32, V, V, I64, V, V, V]
-            pk = lib.scream_pack_w_x3
-            pk.restype = ctypes.c_int
-            pk.argtypes = [V, I32, I32, V, V]
-            libs.append(((tag or "-") + " " + label, fn, pk))
+            lib, pack, gemm = SC.bind(f)
+            libs.append(((tag or "-") + " " + label, gemm, pack))
     print("%-40s" % "variant" + "".join("%16s" % s[0] for s in shapes) + "   (ms | fp32-equivalent TFLOP/s)")
     res = {name: {} for name, *_ in shapes}
     for name, N, K, epi in shapes:
-        A = torch.randn(M, K, device=dev, generator=g); W = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+        A = torch.randn(M, K, device=dev, generator=g).clamp_(-8, 8); W = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
         o = torch.empty(M, N, device=dev); rsd = torch.randn(M, 256, device=dev, generator=g); gam = torch.ones(256, device=dev)
         st = torch.cuda.current_stream().cuda_stream
         calls = []
         for label, fn, pk in libs:  # every build packs with its own packer (the image layout belongs to the kernel)
-            Wp = torch.empty(6 * N * K, device=dev, dtype=torch.uint8)
-            assert pk(W.data_ptr(), N, K, Wp.data_ptr(), st) == 0
-            calls.append((label, Wp, (lambda fn=fn, Wp=Wp: fn(A.data_ptr(), K, Wp.data_ptr(), o.data_ptr(), N, M, N, K, epi, 512 if epi == ops.EPI_ELU1 else 0,
-                                                                 None, rsd.data_ptr(), 256, gam.data_ptr(), gam.data_ptr(), st))))
+            Wp, w_exp = pk(W, st)
+            calls.append((label, Wp, (lambda fn=fn, Wp=Wp, w_exp=w_exp: fn(A, Wp, w_exp, o, M, N, K, epi, 512 if epi == ops.EPI_ELU1 else 0, rsd, gam, st))))
         for label, _, call in calls:
             assert call() == 0
         torch.cuda.synchronize()

@@ -5,10 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from scream_amd import _lib, ops
 dev = "cuda:0"
-planes = ops.split_planes
+planes = ops.pack_w
 
 def x3(A, Wp, N, epi=ops.EPI_NONE, **kw):
-    return ops.gemm_x3(A, Wp, epi, **kw)
+    return ops.gemm_split(A, Wp, epi, **kw)
 
 g = torch.Generator(device=dev).manual_seed(0)
 for (M, N, K) in [(512, 256, 256), (512, 1024, 1024)]:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Energy per launch of the ablation variants of gemm_x3_kernel (tools/x3_ablate.py build first): rocm-smi power and
+"""Energy per launch of the ablation variants of gemm_split_kernel (X3_SPLIT=h2 | x3) (tools/x3_ablate.py build first): rocm-smi power and
 sclk sampled while each variant runs for ~2.5 s on the FFN 256->1024 shape.  Under the 1400 W cap, time follows energy."""
 import ctypes, os, re, subprocess, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,11 +8,12 @@ import torch
 from scream_amd import ops
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import x3_ablate
+import _split_ctypes as SC
 dev = "cuda:0"; M = 327680
 shape = os.environ.get("X3_SHAPE", "ffn1")
 N, K, epi = {"ffn1": (1024, 256, ops.EPI_RELU), "ffn2": (256, 1024, ops.EPI_RES_LN), "qkv": (768, 256, ops.EPI_ELU1)}[shape]
 g = torch.Generator(device=dev).manual_seed(0)
-A = torch.randn(M, K, device=dev, generator=g); W = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+A = torch.randn(M, K, device=dev, generator=g).clamp_(-8, 8); W = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
 o = torch.empty(M, N, device=dev); r = torch.randn(M, 256, device=dev, generator=g); gam = torch.ones(256, device=dev)
 V, I64, I32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
 samples, stop = [], False
@@ -28,15 +29,10 @@ print("%-28s %9s %9s %9s %10s   (%s, M=%d; idle power ~296 W)" % ("variant", "ms
 for bits, label in x3_ablate.VARIANTS:
     f = os.path.join(ROOT, "tools", "_abl" + tag, "x3_%d.so" % bits)
     if not os.path.exists(f): continue
-    lib = ctypes.CDLL(f)
-    fn = lib.scream_gemm_x3_f32; fn.restype = ctypes.c_int
-    fn.argtypes = [V, I64, V, V, I64, I64, I32, I32, I32, I32, V, V, I64, V, V, V]
-    pk = lib.scream_pack_w_x3; pk.restype = ctypes.c_int; pk.argtypes = [V, I32, I32, V, V]
-    Wp = torch.empty(6 * N * K, device=dev, dtype=torch.uint8)
+    lib, pack, gemm = SC.bind(f)
     st = torch.cuda.current_stream().cuda_stream
-    assert pk(W.data_ptr(), N, K, Wp.data_ptr(), st) == 0
-    call = lambda: fn(A.data_ptr(), K, Wp.data_ptr(), o.data_ptr(), N, M, N, K, epi, 512 if epi == ops.EPI_ELU1 else 0, None,
-                      r.data_ptr(), 256, gam.data_ptr(), gam.data_ptr(), st)
+    Wp, w_exp = pack(W, st)
+    call = lambda: gemm(A, Wp, w_exp, o, M, N, K, epi, 512 if epi == ops.EPI_ELU1 else 0, r, gam, st)
     call(); torch.cuda.synchronize(); time.sleep(0.5)
     t0 = time.time(); n = 0
     while time.time() - t0 < 2.5:

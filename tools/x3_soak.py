@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
-"""Soak test: the x3 GEMM against the fp32-MFMA GEMM on random (M, epilogue) draws for a fixed wall time, on two
-streams at once (the lanes configuration).  A mismatch is re-checked against torch on the default stream to tell
+"""Soak test: the split GEMM (a random one of its two operand splits per draw: 2 x fp16 / 3 x bf16) against the fp32-MFMA GEMM
+on random (M, epilogue) draws for a fixed wall time, on two streams at once (the lanes configuration).  A mismatch is re-checked against torch on the default stream to tell
 which kernel is off.  usage: x3_soak.py [seconds]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from scream_amd import ops
+from scream_amd import ops, scales
 dev = "cuda:0"; secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0); g = torch.Generator(device=dev).manual_seed(0)
 Ws = {(N, K): torch.randn(N, K, device=dev, generator=g) / K ** 0.5 for N, K in [(256, 256), (1024, 256), (256, 1024), (768, 256), (512, 64)]}
-Wp = {k: ops.split_planes(w) for k, w in Ws.items()}
+Wp = {(k, sp): ops.pack_w(w, sp) for k, w in Ws.items() for sp in (ops.SPLIT_H2, ops.SPLIT_BF3)}
+A_EXP = scales.exp_for(8.0)  # the activations below are clamped to |a| <= 8: the fp16 split's exponent without a device sync
 torch.cuda.synchronize()
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 t0 = time.time(); n = 0; worst = 0.0
@@ -20,11 +21,12 @@ while time.time() - t0 < secs:
         M = int(rng.integers(1, 1200)) * 128
         epi = [ops.EPI_NONE, ops.EPI_RELU, ops.EPI_RES_LN][rng.integers(3)] if N == 256 else [ops.EPI_NONE, ops.EPI_RELU][rng.integers(2)]
         with torch.cuda.stream(st):
-            A = torch.randn(M, K, device=dev)
+            A = torch.randn(M, K, device=dev).clamp_(-8.0, 8.0)
+            sp = (ops.SPLIT_H2, ops.SPLIT_BF3)[rng.integers(2)]
             kw = {}
             if epi == ops.EPI_RES_LN:
                 kw = dict(residual=torch.randn(M, 256, device=dev), gamma=torch.randn(256, device=dev), beta=torch.randn(256, device=dev))
-            a = ops.gemm_x3(A, Wp[(N, K)], epi, **kw)
+            a = ops.gemm_split(A, Wp[((N, K), sp)], epi, a_exp=A_EXP, **kw)
             b = ops.gemm_f32(A, Ws[(N, K)], epi, **kw)
             jobs.append((M, N, K, epi, (a - b).abs().max(), b.abs().max(), A, a, b, kw))
     torch.cuda.synchronize()

@@ -1,33 +1,32 @@
 #!/usr/bin/env python3
-"""In-kernel s_memtime stamps of gemm_x3_kernel (third output tile of every block): where a k-tile's time goes.
+"""In-kernel s_memtime stamps of gemm_split_kernel (X3_SPLIT=h2 | x3; third output tile of every block): where a k-tile's time goes.
    build: hipcc ... -DX3_STAMPS -> tools/_abl_stamps/x3_0.so (python tools/x3_stamps.py build);  run on the GPU."""
 import ctypes, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "tools", "_abl_stamps", "x3_0.so")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _split_ctypes as SC
 if sys.argv[1:] == ["build"]:
+    import asm_inflight_check as chk
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-DX3_STAMPS",
-                           os.path.join(ROOT, "scream_amd/csrc/gemm_x3.hip"), "-o", SO])
+    src = os.path.join(ROOT, SC.SRC)
+    assert chk.verify_source(src, ["-DX3_STAMPS"], SO[:-3] + ".s", SC.KERNEL) == 12  # never launch unverified counted waits
+    subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-DX3_STAMPS", src, "-o", SO])
     sys.exit(0)
 sys.path.insert(0, ROOT)
 import torch
 from scream_amd import ops
-lib = ctypes.CDLL(SO)
-V, I64, I32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
-fn = lib.scream_gemm_x3_f32; fn.restype = ctypes.c_int
-fn.argtypes = [V, I64, V, V, I64, I64, I32, I32, I32, I32, V, V, I64, V, V, V]
-pk = lib.scream_pack_w_x3; pk.restype = ctypes.c_int; pk.argtypes = [V, I32, I32, V, V]
+lib, pack, gemm = SC.bind(SO)
 dev = "cuda:0"; M = 327680
 g = torch.Generator(device=dev).manual_seed(0)
 for name, N, K, epi in [("ffn1", 1024, 256, ops.EPI_RELU), ("merge", 256, 256, ops.EPI_RES_LN), ("ffn2", 256, 1024, ops.EPI_RES_LN)]:
-    A = torch.randn(M, K, device=dev, generator=g); W = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    A = torch.randn(M, K, device=dev, generator=g).clamp_(-8, 8); W = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
     o = torch.empty(M, N, device=dev); r = torch.randn(M, 256, device=dev, generator=g); gam = torch.ones(256, device=dev)
-    Wp = torch.empty(6 * N * K, device=dev, dtype=torch.uint8)
     st = torch.cuda.current_stream().cuda_stream
-    assert pk(W.data_ptr(), N, K, Wp.data_ptr(), st) == 0
+    Wp, w_exp = pack(W, st)
     for _ in range(3):
-        assert fn(A.data_ptr(), K, Wp.data_ptr(), o.data_ptr(), N, M, N, K, epi, 0, None, r.data_ptr(), 256, gam.data_ptr(), gam.data_ptr(), st) == 0
+        assert gemm(A, Wp, w_exp, o, M, N, K, epi, 0, r, gam, st) == 0
     torch.cuda.synchronize()
     buf = np.zeros(256 * 8 * 160, dtype=np.int64)
     assert lib.scream_x3_stamps_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
