@@ -105,7 +105,10 @@ int scream_kv_finalize(const float* kv_partial, const int32_t* cloud_row0, const
  * kernel stages it in LDS.  A, C, residual and bias stay fp32.  M % 128 == 0, N % 256 == 0, K = 64 + 192 j (64, 256, 448, ...,
  * 1024: the k-loop rotates three operand register sets over two LDS stages, so the k-tile count K/32 is even and 2 mod 3;
  * anything else is SCREAM_EUNSUPPORTED).  A row-block [n0, n0 + n) of W must be packed on its own to be used as a GEMM
- * operand on its own.  layout (SCREAM_LAYOUT_* bits): A fragment-major needs lda == K == 256; C fragment-major applies to the
+ * operand on its own.  scream_gemm_qkv_split_f32 also takes N = 512 L with n_q == 0: the key/value projections of L layers
+ * applied to the SAME rows as one GEMM (the cross stage's target side: the target features are frozen after the stem,
+ * models/pointnet.py:53-57); W is then the L matrices [k heads 0-3 | v 0-3 | k 4-7 | v 4-7] stacked, and layer l's partials
+ * are written at kv_partial + l * (M/128) * 8 * 1056 floats.  layout (SCREAM_LAYOUT_* bits): A fragment-major needs lda == K == 256; C fragment-major applies to the
  * activated tile of an ELU1 / QKV epilogue with n_act == ldc == 256 (the queries). */
 #define SCREAM_SPLIT_H2 2
 #define SCREAM_SPLIT_BF3 3
@@ -150,8 +153,12 @@ int64_t scream_tail_image_bytes(int32_t split);
 int64_t scream_kv_image_bytes(void);
 int scream_pack_tail(const float* Wm, const float* W1, const float* W2, int32_t split, const scream_tail_exps_t* exps,
                      void* tail_image, void* stream);
+/* n_layers > 1: the partials of a batched key/value projection (scream_gemm_qkv_split_f32 with N = 512 n_layers): layer l
+ * reads kv_partial + l * partial_layer_stride floats ((M/128) * 8 * 1056 of that GEMM) and writes its n_kv cloud images at
+ * kv_image + l * image_layer_stride bytes.  n_layers == 1: strides ignored. */
 int scream_kv_finalize_x3(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
-                          int64_t row_base, int32_t cloud_begin, int32_t n_kv, void* kv_image, void* stream);
+                          int64_t row_base, int32_t cloud_begin, int32_t n_kv, void* kv_image, int32_t n_layers,
+                          int64_t partial_layer_stride, int64_t image_layer_stride, void* stream);
 int scream_layer_tail_f32(const float* Q, const void* kv_image, const int32_t* tile_cloud,
                           int32_t kv_cloud_offset, const int32_t* cloud_len, const float* x,
                           const void* tail_image, const float* g1, const float* b1, const float* g2,
@@ -233,6 +240,12 @@ typedef struct {
     int32_t gemm_split;
     /* SCREAM_SPLIT_H2 only: exponents of the coordinate MLP's two GEMMs (input: the last LayerNorm2 / relu(c0 . + b0)) */
     int32_t e_c0x, e_c0w, e_c2x, e_c2w;
+    /* Fused-tail models only; may be NULL.  scream_pack_w_split image of the n_cross cross layers' wkv matrices stacked
+     * ([512 n_cross, 256]; exponent e_wkv_cross): the forward then projects the frozen target features for ALL cross layers in
+     * one launch right after the stem (and finalises their K^T V images in one) instead of once per layer, and ignores the
+     * cross layers' wkv / e_wkv. */
+    const float* wkv_cross;
+    int32_t e_wkv_cross;
 } scream_model_t;
 
 typedef struct {
@@ -249,9 +262,10 @@ typedef struct {
 
 /* Bytes of scratch scream_forward needs for this batch geometry.  fused_tail != 0: every layer carries a tail image (the
  * default of the split backends) -- 3 KB per row (two feature buffers and Q'); otherwise the attention output, LayerNorm1
- * output and FFN hidden buffers of the unfused chain are carved as well (9 KB per row). */
+ * output and FFN hidden buffers of the unfused chain are carved as well (9 KB per row).  n_cross_batched: scream_model_t.n_cross
+ * when wkv_cross is set (partials and images of every cross layer's target-side K^T V live side by side), else 0. */
 int64_t scream_forward_workspace_bytes(int64_t rows_src, int64_t rows_total, int32_t n_pairs,
-                                       int32_t max_chunks, int32_t fused_tail);
+                                       int32_t max_chunks, int32_t fused_tail, int32_t n_cross_batched);
 
 /* src_pred [rows_src,3] (padding rows hold don't-care values).  If feats_out != NULL the final
  * source features [rows_src,256] are copied there (test hook).  trace: NULL, or a handle from

@@ -39,7 +39,8 @@ class ModelT(C.Structure):
                 ("layers_host", C.POINTER(LayerT)), ("c0_w", C.c_void_p), ("c0_b", C.c_void_p),
                 ("c2_w", C.c_void_p), ("c2_b", C.c_void_p), ("c4_w", C.c_void_p), ("c4_b", C.c_void_p),
                 ("stem_tgt_layers_host", C.POINTER(LayerT)), ("gemm_split", C.c_int32),
-                ("e_c0x", C.c_int32), ("e_c0w", C.c_int32), ("e_c2x", C.c_int32), ("e_c2w", C.c_int32)]
+                ("e_c0x", C.c_int32), ("e_c0w", C.c_int32), ("e_c2x", C.c_int32), ("e_c2w", C.c_int32),
+                ("wkv_cross", C.c_void_p), ("e_wkv_cross", C.c_int32)]
 
 
 class BatchT(C.Structure):
@@ -62,14 +63,14 @@ SIGNATURES = {
     "scream_tail_image_bytes": (C.c_int64, [I32]),
     "scream_kv_image_bytes": (C.c_int64, []),
     "scream_pack_tail": (C.c_int, [V, V, V, I32, C.POINTER(TailExpsT), V, V]),
-    "scream_kv_finalize_x3": (C.c_int, [V, V, V, I64, I32, I32, V, V]),
+    "scream_kv_finalize_x3": (C.c_int, [V, V, V, I64, I32, I32, V, I32, I64, I64, V]),
     "scream_layer_tail_f32": (C.c_int, [V, V, V, I32, V, V, V, V, V, V, V, V, I64, I32, C.POINTER(TailExpsT), V]),
     "scream_act_layout": (C.c_int, [V, V, I64, I32, V]),
     "scream_pe_embed_ln": (C.c_int, [V, V, V, V, V, V, V, V, V, I64, V]),
     "scream_kv_reduce": (C.c_int, [V, V, I64, I64, V, V, I32, I32, I32, V, V, V]),
     "scream_attn_apply": (C.c_int, [V, I64, V, V, I32, V, V, I64, I64, V]),
     "scream_coor_head": (C.c_int, [V, V, V, V, I64, V]),
-    "scream_forward_workspace_bytes": (C.c_int64, [I64, I64, I32, I32, I32]),
+    "scream_forward_workspace_bytes": (C.c_int64, [I64, I64, I32, I32, I32, I32]),
     "scream_forward": (C.c_int, [C.POINTER(ModelT), C.POINTER(BatchT), V, I64, V, V, V, V]),
     "scream_trace_create": (C.c_void_p, [I32]),
     "scream_trace_destroy": (None, [V]),

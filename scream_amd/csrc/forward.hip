@@ -18,13 +18,16 @@ constexpr int KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;
 struct Workspace {
     float *x0, *x1, *q, *att, *m1, *hid, *kvp, *kv;
     char* kvimg;  // per-cloud operand images of the fused layer tail
+    float* kvp_cross;   // batched target-side projection of the cross stage: K^T V partials of every cross layer ...
+    char* kvimg_cross;  // ... and their images, [layer][target cloud]
+    int64_t kvp_cross_stride, kvimg_cross_stride;  // floats / bytes per layer
     int64_t bytes;
 };
 
 // fused: every layer runs its tail as one launch -- the attention output, LayerNorm1 output and FFN hidden buffers of the
 // unfused chain (6 KB per row) are then not carved (3 KB per row remain: two feature buffers and Q'); the coordinate MLP's
 // two intermediates go into Q' and the idle feature buffer.
-Workspace carve(void* base, int64_t rows_total, int32_t n_pairs, int32_t max_chunks, bool fused) {
+Workspace carve(void* base, int64_t rows_src, int64_t rows_total, int32_t n_pairs, int32_t max_chunks, bool fused, int32_t n_cross_batched) {
     Workspace w;
     float* p = reinterpret_cast<float*>(base);
     auto take = [&](int64_t n) {
@@ -41,6 +44,10 @@ Workspace carve(void* base, int64_t rows_total, int32_t n_pairs, int32_t max_chu
     w.kvp = take(rows_total / SCREAM_ROW_TILE * SCREAM_NHEAD * KV_ELEMS);  // one K^T V partial per 128-row tile and head
     w.kv = take((int64_t)2 * n_pairs * SCREAM_NHEAD * KV_ELEMS);
     w.kvimg = reinterpret_cast<char*>(take((int64_t)2 * n_pairs * scream_kv_image_bytes() / 4));
+    w.kvp_cross_stride = (rows_total - rows_src) / SCREAM_ROW_TILE * SCREAM_NHEAD * KV_ELEMS;
+    w.kvimg_cross_stride = (int64_t)n_pairs * scream_kv_image_bytes();
+    w.kvp_cross = take(n_cross_batched * w.kvp_cross_stride);
+    w.kvimg_cross = reinterpret_cast<char*>(take(n_cross_batched * w.kvimg_cross_stride / 4));
     w.bytes = (p - reinterpret_cast<float*>(base)) * (int64_t)sizeof(float);
     return w;
 }
@@ -134,7 +141,7 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
     if (c.frag) {  // apply + merge + norm1 + FFN + norm2 in one launch
         {
             Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
-            TRY(scream_kv_finalize_x3(kvp, b.cloud_row0, b.cloud_len, row0, cloud_begin, n_clouds, w.kvimg, c.st));
+            TRY(scream_kv_finalize_x3(kvp, b.cloud_row0, b.cloud_len, row0, cloud_begin, n_clouds, w.kvimg, 1, 0, 0, c.st));
         }
         Scope sc(c.tr, TR_TAIL_FUSED, rows, 9 * D, D, c.st);  // merge (256) + FFN up and down (2 x 1024) output columns per row
         return scream_layer_tail_f32(qr, w.kvimg, b.tile_cloud + row0 / SCREAM_ROW_TILE, 0, b.cloud_len, xr, L.tail, L.g1,
@@ -152,17 +159,40 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
     return mha_tail(c, L, w, xr, y + row0 * D, row0, rows);
 }
 
+// The target side of EVERY cross layer at once (fused-tail models with scream_model_t.wkv_cross): the target features are
+// frozen after the stem (models/pointnet.py:53-57), so the n_cross key/value projections read the same rows -- one GEMM with
+// N = 512 n_cross (12 n_cross column tiles per 256-row tile instead of n_cross launches of two: the persistent grid's partial
+// last round shrinks from 15 % to under 2 %) and one finalize launch for all n_cross x n_pairs K^T V images.
+int cross_kv_all(const Ctx& c, const scream_model_t& m, const scream_batch_t& b, const Workspace& w, const float* x_tgt) {
+    const int64_t rs = b.rows_src, rt = b.rows_total - b.rows_src;
+    const scream_layer_t& L0 = m.layers_host[m.n_self + 1];  // every cross layer sees the same target features: one e_xkv
+    TRY(gemm_qkv(c, x_tgt, m.wkv_cross, nullptr, rt, 2 * D * m.n_cross, 0, b, rs, w.kvp_cross, L0.e_xkv, m.e_wkv_cross));
+    Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
+    // images are indexed by ABSOLUTE cloud (targets are clouds n_pairs .. 2 n_pairs - 1): layer l's block starts n_pairs images early
+    return scream_kv_finalize_x3(w.kvp_cross, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs,
+                                 w.kvimg_cross - (int64_t)b.n_pairs * scream_kv_image_bytes(), m.n_cross, w.kvp_cross_stride,
+                                 w.kvimg_cross_stride, c.st);
+}
+
 // Cross attention: queries from the source rows, keys/values from the frozen target rows (transformer.py:130).
+// kvimg_layer != NULL: this layer's target-side K^T V images were already built by cross_kv_all (image of target cloud j at
+// kvimg_layer + j * scream_kv_image_bytes()).
 int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x_src,
-              const float* x_tgt, float* y) {
+              const float* x_tgt, float* y, const char* kvimg_layer) {
     const int64_t rs = b.rows_src, rt = b.rows_total - b.rows_src;
     TRY(gemm(c, x_src, D, L.wq, w.q, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr, L.e_xq, L.e_wq,
              c.frag ? (SCREAM_LAYOUT_A_FRAG | SCREAM_LAYOUT_C_FRAG) : 0));
+    if (c.frag && kvimg_layer) {
+        Scope sc(c.tr, TR_TAIL_FUSED, rs, 9 * D, D, c.st);
+        // tile_cloud holds source cloud i for the source tiles; its target cloud's image is entry i of this layer's block
+        return scream_layer_tail_f32(w.q, kvimg_layer, b.tile_cloud, 0, b.cloud_len + b.n_pairs, x_src, L.tail, L.g1, L.b1, L.g2,
+                                     L.b2, y, rs, c.split, &L.tail_exps, c.st);
+    }
     TRY(gemm_qkv(c, x_tgt, L.wkv, nullptr, rt, 2 * D, 0, b, rs, w.kvp, L.e_xkv, L.e_wkv));
     if (c.frag) {
         {
             Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
-            TRY(scream_kv_finalize_x3(w.kvp, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs, w.kvimg, c.st));
+            TRY(scream_kv_finalize_x3(w.kvp, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs, w.kvimg, 1, 0, 0, c.st));
         }
         Scope sc(c.tr, TR_TAIL_FUSED, rs, 9 * D, D, c.st);
         return scream_layer_tail_f32(w.q, w.kvimg, b.tile_cloud, b.n_pairs, b.cloud_len, x_src, L.tail, L.g1, L.b1, L.g2, L.b2,
@@ -240,9 +270,9 @@ extern "C" int scream_trace_read_starts(void* trace, int32_t max_records, float*
 }
 
 extern "C" int64_t scream_forward_workspace_bytes(int64_t rows_src, int64_t rows_total, int32_t n_pairs,
-                                                  int32_t max_chunks, int32_t fused_tail) {
-    if (rows_src < 0 || rows_total < rows_src || n_pairs < 0 || max_chunks < 0) return SCREAM_EINVAL;
-    return carve(nullptr, rows_total, n_pairs, max_chunks, fused_tail != 0).bytes + 256;
+                                                  int32_t max_chunks, int32_t fused_tail, int32_t n_cross_batched) {
+    if (rows_src < 0 || rows_total < rows_src || n_pairs < 0 || max_chunks < 0 || n_cross_batched < 0) return SCREAM_EINVAL;
+    return carve(nullptr, rows_src, rows_total, n_pairs, max_chunks, fused_tail != 0, n_cross_batched).bytes + 256;
 }
 
 extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t* batch, void* workspace,
@@ -262,7 +292,9 @@ extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t*
         for (int i = 0; i < m.n_self; ++i, ++n_layers) n_tail += m.stem_tgt_layers_host[i].tail != nullptr;
     SCREAM_REQUIRE(n_tail == 0 || (n_tail == n_layers && m.gemm_split != 0), SCREAM_EINVAL);
     uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
-    const Workspace w = carve(reinterpret_cast<void*>(base), b.rows_total, b.n_pairs, b.max_chunks, n_tail > 0);
+    const bool batched_kv = n_tail > 0 && m.wkv_cross != nullptr && m.n_cross > 0;
+    const Workspace w = carve(reinterpret_cast<void*>(base), b.rows_src, b.rows_total, b.n_pairs, b.max_chunks, n_tail > 0,
+                              batched_kv ? m.n_cross : 0);
     SCREAM_REQUIRE((int64_t)(base - reinterpret_cast<uintptr_t>(workspace)) + w.bytes <= workspace_bytes, SCREAM_EINVAL);
     const Ctx c{stream, reinterpret_cast<Trace*>(trace), m.gemm_split, n_tail > 0};
 
@@ -287,12 +319,13 @@ extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t*
         nxt = t;
     }
     const float* x_tgt = cur + rs * D;  // frozen from here on: the cross stage only writes rows [0, rs)
+    if (batched_kv) TRY(cross_kv_all(c, m, b, w, x_tgt));
     for (int i = 0; i < 2 * m.n_cross; ++i) {  // pointnet.py:53-57
         const scream_layer_t& L = m.layers_host[m.n_self + i];
         if (i % 2 == 0) {
             TRY(mha_self(c, L, b, w, cur, nxt, 0, rs, 0, b.n_pairs));
         } else {
-            TRY(mha_cross(c, L, b, w, cur, x_tgt, nxt));
+            TRY(mha_cross(c, L, b, w, cur, x_tgt, nxt, batched_kv ? w.kvimg_cross + (i / 2) * w.kvimg_cross_stride : nullptr));
         }
         float* t = cur;
         cur = nxt;

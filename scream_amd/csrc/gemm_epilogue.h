@@ -22,6 +22,9 @@ struct EpiArgs {
     // SCREAM_EPI_ELU1 / SCREAM_EPI_QKV, x3 kernel only: the activated tile (the 256 query columns) is written in the
     // FRAGMENT-major activation layout (SCREAM_ACT_FRAG, include/scream_hip.h) that tail_x3.hip reads; ldc must be 256
     int c_frag;
+    // SCREAM_EPI_QKV with more than one key/value tile PAIR (the cross stage's six target-side projections as one GEMM,
+    // N = n_act + 512 L): floats between the partial arrays of consecutive layers
+    int64_t kv_layer_stride;
 };
 
 constexpr int KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;
@@ -59,8 +62,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[8], float* slabs, in
         if (rows_exist) {
             const int cloud = ep.tile_cloud[(ep.row_base + mrow) / SCREAM_ROW_TILE];
             valid_w = ep.cloud_len[cloud] - (int)(ep.row_base + mrow - ep.cloud_row0[cloud]) - wg * 32;  // real tokens in this wave's rows
-            const int hb = (n0_cur - ep.n_act) / BN * 4;
-            part += ((int64_t)(mrow / SCREAM_ROW_TILE) * SCREAM_NHEAD + hb) * KV_ELEMS;
+            const int kvt = (n0_cur - ep.n_act) / BN;  // key/value tile: layer kvt / 2, heads 4 (kvt % 2) .. + 3
+            part += (int64_t)(kvt >> 1) * ep.kv_layer_stride + ((int64_t)(mrow / SCREAM_ROW_TILE) * SCREAM_NHEAD + (kvt & 1) * 4) * KV_ELEMS;
         }
         constexpr int HPR = NWAVES == 4 ? 2 : 1;  // heads per LDS round: 8 x 1056 floats of scratch either way
 #pragma unroll

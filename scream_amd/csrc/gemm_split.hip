@@ -453,14 +453,15 @@ extern "C" int scream_gemm_qkv_split_f32(const float* A, int64_t lda, const void
     const SplitArgs sa{split, a_exp, w_exp};
     SCREAM_REQUIRE(split_args_ok(sa), SCREAM_EINVAL);
     SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K >= 64 && K % 64 == 0 && (K / 32 - 2) % 3 == 0, SCREAM_EUNSUPPORTED);  // K = 64 + 192 j
-    SCREAM_REQUIRE((n_q == 0 || n_q == XBN) && N == n_q + 2 * XBN && row_base >= 0 && row_base % SCREAM_ROW_TILE == 0,
-                   SCREAM_EUNSUPPORTED);
+    // N = n_q + 512 L: L key/value tile pairs; L > 1 (several layers' key/value projections of the same rows) only without queries
+    SCREAM_REQUIRE((n_q == 0 || n_q == XBN) && N > n_q && (N - n_q) % (2 * XBN) == 0 && (n_q == 0 || N == n_q + 2 * XBN) && row_base >= 0 &&
+                       row_base % SCREAM_ROW_TILE == 0, SCREAM_EUNSUPPORTED);
     SCREAM_REQUIRE(n_q == 0 || (Q && ldq >= n_q && ldq % 4 == 0 && (reinterpret_cast<uintptr_t>(Q) & 15) == 0), SCREAM_EINVAL);
     SCREAM_REQUIRE(lda >= K && lda % 4 == 0, SCREAM_EINVAL);
     SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W_packed) & 15) == 0, SCREAM_EINVAL);
     SCREAM_REQUIRE(!(layout & SCREAM_LAYOUT_C_FRAG) || n_q == XBN, SCREAM_EUNSUPPORTED);
     if (int rc = check_layout(layout, lda, n_q ? ldq : SCREAM_D_MODEL, K, SCREAM_EPI_QKV, n_q ? n_q : SCREAM_D_MODEL)) return rc;
     EpiArgs ep{n_q, nullptr, nullptr, 0, nullptr, nullptr, kv_partial, tile_cloud, cloud_row0, cloud_len, row_base,
-               (layout & SCREAM_LAYOUT_C_FRAG) ? 1 : 0};
+               (layout & SCREAM_LAYOUT_C_FRAG) ? 1 : 0, (M / SCREAM_ROW_TILE) * SCREAM_NHEAD * (int64_t)KV_ELEMS};
     return launch_split<SCREAM_EPI_QKV>(A, lda, W_packed, Q, ldq, M, N, K, ep, as_stream(stream), layout & SCREAM_LAYOUT_A_FRAG, sa);
 }

@@ -55,6 +55,10 @@
 
 #include "ring.h"
 
+#ifndef T_DEFER_H2
+#define T_DEFER_H2 2  // SplitH2: MFMA groups of a stage deferred across the barrier into the next stage (1 or 2)
+#endif
+
 // -DT_STAMPS (tools/tail_stamps.py): s_memtime stamps of the phases of the SECOND tile of every block, lane 0 of each wave.
 // Diagnostic build only -- tools/tail_stamps.py runs tools/asm_inflight_check.py on it first: the extra registers can push
 // hipcc into spilling a pending load destination (it did, with one stamp per stage).
@@ -106,10 +110,10 @@ struct TailScales {
 };
 
 // merge stage h (h >= 1): which quarter of the x-segment add rides in group g (-1: none) -- the last four groups of
-// 14 .. 8 that do not accumulate into tile h - 1
-__device__ __forceinline__ constexpr int xadd_slot(int h, int g) {
+// 15 - nd .. 8 (nd = deferred groups of the stage) that do not accumulate into tile h - 1
+__device__ __forceinline__ constexpr int xadd_slot(int h, int g, int nd) {
     int n = 0;
-    for (int c = 14; c >= 8; --c) {
+    for (int c = 15 - nd; c >= 8; --c) {
         if ((c >> 1) == h - 1) continue;
         if (c == g) return n < 4 ? n : -1;
         ++n;
@@ -133,6 +137,11 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
     constexpr int STAGE = stage_bytes<SP>();
     constexpr int PIECES = wave_pieces<SP>();  // LDS-DMA pieces per wave and stage = what a counted ring wait leaves in flight
     constexpr int NV_MERGE = SP::NPROD >= 6 ? 6 : 8;  // ride slots behind every MFMA of a merge stage (32 cycles / 4 per VALU issue)
+    // The last ND MFMA groups of every stage are DEFERRED across the barrier (below): 192 cycles of work on register operands
+    // must cover the barrier skew and the first fragment reads of the next stage -- one group of six bf16 products, two groups
+    // of three fp16 products.
+    constexpr int ND = SP::NPROD >= 6 ? 1 : T_DEFER_H2;
+    constexpr int NG = 16 - ND;  // groups issued inside their own stage
     __shared__ __attribute__((aligned(16))) char smem[T_SLOTS * STAGE + 4096];  // the ring + the norm parameters, the ONLY LDS object
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -292,11 +301,11 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         unsigned marks[16] = {};
 #endif
         TSTAMP(0);  // tile start
-        // The last MFMA group of every stage is DEFERRED across the barrier: its weight fragments are read into wfd, and
-        // the next stage issues it right after the first fragment reads of its own -- a group of work with register
+        // The last MFMA group(s) of every stage are DEFERRED across the barrier: their weight fragments are read into wfd, and
+        // the next stage issues them right after the first fragment reads of its own -- work with register
         // operands exactly where a lone in-order wave otherwise waits for the LDS (tools/tail_stamps.py: 3.8 k cycles per
-        // 3.07 k-cycle stage of the bf16 kernel).  `flush` arguments below name the deferred group of the preceding stage.
-        V wfd[NP];
+        // 3.07 k-cycle stage of the bf16 kernel).  `flush` arguments below name the deferred groups of the preceding stage.
+        V wfd[ND][NP];
         f32x16 acc[8];  // (started by the first product of merge stage 0 / of the first down stage: no zeroing moves)
         // the block's next tile (its heads 0 and 1 are applied under / right after this tile's last stage)
         const int tile_next = tile + (int)gridDim.x;
@@ -349,11 +358,11 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
                 for (int p = 0; p < NP; ++p) wf[g0][p] = ld_frag<V>(wb + (p * 16 + g0) * 1024);
             flush();
 #pragma unroll
-            for (int g = 0; g < 15; ++g) {  // g = blk * 2 + s2; group 15 is deferred to the next stage
+            for (int g = 0; g < NG; ++g) {  // g = blk * 2 + s2; the last ND groups are deferred to the next stage
                 if (g + T_PF - 1 < 16) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
-                        (g + T_PF - 1 == 15 ? wfd[p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag<V>(wb + (p * 16 + g + T_PF - 1) * 1024);
+                        (g + T_PF - 1 >= NG ? wfd[g + T_PF - 1 - NG][p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag<V>(wb + (p * 16 + g + T_PF - 1) * 1024);
                 }
                 if (g == 4 && RIDE && h + 2 < 8) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
                 // the norm1 residual: segment h - 1 joins accumulator tile h - 1 in quarters, in late groups that do not
                 // accumulate into that tile (its MFMAs are groups 2h - 2 and 2h - 1)
                 if (h > 0) {
-                    const int pc = xadd_slot(h, g);
+                    const int pc = xadd_slot(h, g, ND);
                     if (pc >= 0 && !(T_ABLATE & 1024)) add_x4(acc[h > 0 ? h - 1 : 0], x_prev, pc, sc.c1);
                 }
                 mfma_group<SP, (h > 0 ? NV_MERGE : 0)>(acc[g >> 1], wf[g % T_PF], ap[g & 1], h == 0 && (g & 1) == 0);
@@ -377,11 +386,17 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         constexpr std::integral_constant<bool, false> no{};
 #define HEAD(n) std::integral_constant<int, n>{}
         auto flush_none = [&]() {};
-        auto flush_mergeA = [&]() { mfma_group<SP, -1>(acc[7], wfd, apA[1]); };  // deferred group of a merge stage of an even head
-        auto flush_mergeB = [&]() { mfma_group<SP, -1>(acc[7], wfd, apB[1]); };
-        //            head   planes  planes of head + 1   Q' consumed (head + 1)   Q' requested (head + 2)   deferred group of
+        // the deferred groups 16 - ND .. 15 of a merge or down stage all accumulate into tile 7; first: the tile starts here
+        auto flush_acc7 = [&](V (&b)[2][NP], bool first) {
+#pragma unroll
+            for (int i = 0; i < ND; ++i) mfma_group<SP, -1>(acc[7], wfd[i], b[(NG + i) & 1], first && ((NG + i) & 1) == 0);
+        };
+        auto flush_mergeA = [&]() { flush_acc7(apA, false); };  // deferred groups of a merge stage of an even head
+        auto flush_mergeB = [&]() { flush_acc7(apB, false); };
+        auto flush_mergeA0 = [&]() { flush_acc7(apA, true); };  // ... of stage 0, which starts the accumulator tiles
+        //            head   planes  planes of head + 1   Q' consumed (head + 1)   Q' requested (head + 2)   deferred groups of
         stage_merge(HEAD(0), apA, apB, qB, qA, flush_none);   // (the previous tile ended flushed)
-        stage_merge(HEAD(1), apB, apA, qA, qB, flush_mergeA);
+        stage_merge(HEAD(1), apB, apA, qA, qB, flush_mergeA0);
         stage_merge(HEAD(2), apA, apB, qB, qA, flush_mergeB);
         stage_merge(HEAD(3), apB, apA, qA, qB, flush_mergeA);
         stage_merge(HEAD(4), apA, apB, qB, qA, flush_mergeB);
@@ -462,11 +477,11 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
                 for (int p = 0; p < NP; ++p) wf[g0][p] = ld_frag<V>(wb + (p * 16 + g0) * 1024);
             flush();
 #pragma unroll
-            for (int g = 0; g < 15; ++g) {  // group 15 (hT += wfd . mp[15]) is deferred to the next stage
+            for (int g = 0; g < NG; ++g) {  // the last ND groups (hT += wfd . mp[g]) are deferred to the next stage
                 if (g + T_PF - 1 < 16) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
-                        (g + T_PF - 1 == 15 ? wfd[p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag<V>(wb + (p * 16 + g + T_PF - 1) * 1024);
+                        (g + T_PF - 1 >= NG ? wfd[g + T_PF - 1 - NG][p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag<V>(wb + (p * 16 + g + T_PF - 1) * 1024);
                 }
                 if (g < PIECES) dma_piece(q + 2, g);
                 mfma_group<SP>(hT, wf[g % T_PF], mp[g], g == 0);
@@ -514,11 +529,11 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
                 for (int p = 0; p < NP; ++p) wf[g0][p] = ld_frag<V>(wb + (p * 16 + g0) * 1024);
             flush();
 #pragma unroll
-            for (int g = 0; g < 15; ++g) {  // g = blk * 2 + s2; group 15 (acc[7] += wfd . hin[1]) is deferred to the next stage
+            for (int g = 0; g < NG; ++g) {  // g = blk * 2 + s2; the last ND groups (acc[7] += wfd . hin[g & 1]) are deferred to the next stage
                 if (g + T_PF - 1 < 16) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
-                        (g + T_PF - 1 == 15 ? wfd[p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag<V>(wb + (p * 16 + g + T_PF - 1) * 1024);
+                        (g + T_PF - 1 >= NG ? wfd[g + T_PF - 1 - NG][p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag<V>(wb + (p * 16 + g + T_PF - 1) * 1024);
                 }
                 if (RIDE == 2 && g == 4) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -533,7 +548,9 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
                     if (g < PIECES) dma_piece(q + 2, g);
                 }
                 if (RIDE == 2) apply_ride(qA, g, apA, S_next, tile_next);
-                if (decltype(with_split)::value && (g & 1) == 0) split_pair(g >> 1, hout);
+                // the relu / split of the h^T tile the previous stage finished: eight pairs, in every other group (in the first
+                // eight groups when group 14 is deferred)
+                if (decltype(with_split)::value && (ND == 1 ? (g & 1) == 0 : g < 8)) split_pair(ND == 1 ? g >> 1 : g, hout);
                 mfma_group<SP>(acc[g >> 1], wf[g % T_PF], hin[g & 1], XADD == 0 && g >= 2 && (g & 1) == 0);
             }
             ++q;
@@ -543,9 +560,13 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         // stage order (= image order): W1_0 | W1_c, W2_{c-1} for c = 1 .. 31 | W2_31.  The norm2 residual: the up stage of
         // chunk c requests x segment c - 1, the down stage of chunk c - 1 that follows adds it (c - 1 < 8) -- the first
         // four pair iterations are peeled so that every accumulator index is a compile-time constant.
-        auto flush_up = [&]() { mfma_group<SP, -1>(hT, wfd, mp[15]); };            // deferred group of an up stage
-        auto flush_downA = [&]() { mfma_group<SP, -1>(acc[7], wfd, hpA[1]); };     // ... of a down stage whose operand was hpA
-        auto flush_downB = [&]() { mfma_group<SP, -1>(acc[7], wfd, hpB[1]); };
+        auto flush_up = [&]() {                                   // deferred groups of an up stage
+#pragma unroll
+            for (int i = 0; i < ND; ++i) mfma_group<SP, -1>(hT, wfd[i], mp[NG + i]);
+        };
+        auto flush_downA = [&]() { flush_acc7(hpA, false); };     // ... of a down stage whose operand was hpA
+        auto flush_downB = [&]() { flush_acc7(hpB, false); };
+        auto flush_downA0 = [&]() { flush_acc7(hpA, true); };     // ... of the tile's first down stage, which starts the accumulator tiles
         stage_up(yes, none, flush_none);
         flush_up();
 #pragma unroll
@@ -555,7 +576,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         stage_down(hpA, hpB, yes, HEAD((c) - 1), ride0, flush_up); /* chunk c - 1, splits c */ \
         stage_up(no, HEAD(c), flA);                                /* chunk c + 1 */         \
         stage_down(hpB, hpA, yes, HEAD(c), ride0, flush_up);       /* chunk c, splits c + 1 */
-        PAIR(1, flush_none, flush_downA) PAIR(3, flush_downB, flush_downA) PAIR(5, flush_downB, flush_downA) PAIR(7, flush_downB, flush_downA)
+        PAIR(1, flush_none, flush_downA0) PAIR(3, flush_downB, flush_downA) PAIR(5, flush_downB, flush_downA) PAIR(7, flush_downB, flush_downA)
 #undef PAIR
         for (int c = 9; c < 31; c += 2) {
             stage_up(no, none, flush_downB);
@@ -703,14 +724,18 @@ __global__ void pack_tail_kernel(const float* __restrict__ Wm, const float* __re
 
 // Sum of the per-128-row-tile K^T V partials of the fused q/k/v GEMM (as kv_finalize_tiles_kernel, attention.hip) written
 // as the operand image of tail_kernel: per cloud and head the A-operand fragments of KV_h^T / S (row m = value index
-// v, contraction index d = chunk_k(step, half, j)) in three bf16 planes, then Ksum as fp32.  grid n_kv * 8, block 1024.
+// v, contraction index d = chunk_k(step, half, j)) in three bf16 planes, then Ksum as fp32.  grid (n_kv * 8, n_layers),
+// block 1024; layer l reads partial + l * partial_layer_stride floats and writes kvimg + l * image_layer_stride bytes.
 __global__ __launch_bounds__(1024) void kv_finalize_x3_kernel(const float* __restrict__ partial,
                                                             const int32_t* __restrict__ cloud_row0,
                                                             const int32_t* __restrict__ cloud_len, int64_t row_base,
-                                                            int cloud_begin, char* __restrict__ kvimg) {
+                                                            int cloud_begin, char* __restrict__ kvimg,
+                                                            int64_t partial_layer_stride, int64_t image_layer_stride) {
     constexpr int KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;
     const int kvi = blockIdx.x / SCREAM_NHEAD, h = blockIdx.x % SCREAM_NHEAD;
     const int cloud = cloud_begin + kvi;
+    partial += (int64_t)blockIdx.y * partial_layer_stride;
+    kvimg += (int64_t)blockIdx.y * image_layer_stride;
     const int t0 = (int)((cloud_row0[cloud] - row_base) / SCREAM_ROW_TILE);
     const int nt = (cloud_len[cloud] + SCREAM_ROW_TILE - 1) / SCREAM_ROW_TILE;
     const float* p = partial + ((int64_t)t0 * SCREAM_NHEAD + h) * KV_ELEMS;
@@ -792,13 +817,15 @@ extern "C" int scream_pack_tail(const float* Wm, const float* W1, const float* W
 }
 
 extern "C" int scream_kv_finalize_x3(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
-                                     int64_t row_base, int32_t cloud_begin, int32_t n_kv, void* kv_image, void* stream) {
+                                     int64_t row_base, int32_t cloud_begin, int32_t n_kv, void* kv_image, int32_t n_layers,
+                                     int64_t partial_layer_stride, int64_t image_layer_stride, void* stream) {
     SCREAM_REQUIRE(kv_partial && cloud_row0 && cloud_len && kv_image, SCREAM_EINVAL);
-    SCREAM_REQUIRE(n_kv >= 0 && cloud_begin >= 0 && row_base >= 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE(n_kv >= 0 && cloud_begin >= 0 && row_base >= 0 && n_layers >= 1 && n_layers <= 65535, SCREAM_EINVAL);
+    SCREAM_REQUIRE(n_layers == 1 || (partial_layer_stride > 0 && image_layer_stride > 0 && image_layer_stride % 16 == 0), SCREAM_EINVAL);
     SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(kv_image) & 15) == 0, SCREAM_EINVAL);
     if (n_kv == 0) return 0;
-    kv_finalize_x3_kernel<<<dim3(n_kv * SCREAM_NHEAD), dim3(1024), 0, as_stream(stream)>>>(kv_partial, cloud_row0, cloud_len, row_base,
-                                                                                         cloud_begin, reinterpret_cast<char*>(kv_image));
+    kv_finalize_x3_kernel<<<dim3(n_kv * SCREAM_NHEAD, n_layers), dim3(1024), 0, as_stream(stream)>>>(
+        kv_partial, cloud_row0, cloud_len, row_base, cloud_begin, reinterpret_cast<char*>(kv_image), partial_layer_stride, image_layer_stride);
     SCREAM_LAUNCH_CHECK();
     return 0;
 }

@@ -100,8 +100,15 @@ class PointTransformer(nn.Module):
     # intermediate activations then go through HBM)
     fused_tail = os.environ.get("SCREAM_FUSED_TAIL", "1") != "0"
 
+    # fused tail only: project the frozen target features for ALL cross layers in one launch after the stem (and finalise their
+    # K^T V images in one) instead of once per cross layer; SCREAM_BATCHED_CROSS_KV=0 keeps the per-layer launches
+    batched_cross_kv = os.environ.get("SCREAM_BATCHED_CROSS_KV", "1") != "0"
+
+    def _fused_cfg(self, split) -> bool:
+        return bool(split and self.fused_tail)
+
     def _signature(self):
-        return (self.gemm_backend, self.fused_tail) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.gemm_backend, self.fused_tail, self.batched_cross_kv) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _layer_inputs(self):
         """(in_q, in_kv) per layer of _layer_modules() [+ per layer of _stem_tgt_modules()] and the coordinate MLP's input:
@@ -193,10 +200,18 @@ class PointTransformer(nn.Module):
         (mt.c0_w, mt.e_c0w), mt.c0_b = dev_mat(c0w), dev_f32(self.coor_mlp[0].bias)
         (mt.c2_w, mt.e_c2w), mt.c2_b = dev_mat(c2w), dev_f32(self.coor_mlp[2].bias)
         mt.c4_w, mt.c4_b = dev_f32(self.coor_mlp[4].weight[:, :, 0]), dev_f32(self.coor_mlp[4].bias)
+        mt.wkv_cross = None
+        if self._fused_cfg(split) and self.batched_cross_kv and self.cross_layer_num > 0:
+            # the cross layers' key/value projections of the (frozen) target features as ONE GEMM, models/pointnet.py:53-57
+            cross = [m for i, m in enumerate(self.cross) if i % 2 == 1]
+            stack = torch.cat([torch.cat([c.layer.k_proj.weight[:128], c.layer.v_proj.weight[:128], c.layer.k_proj.weight[128:],
+                                          c.layer.v_proj.weight[128:]], dim=0) for c in cross], dim=0)
+            mt.wkv_cross, mt.e_wkv_cross = dev_mat(stack)
         if split == _lib.SPLIT_H2:  # coor_mlp (models/pointnet.py:27-33): LayerNorm2 output -> Conv1d + bias, relu -> Conv1d
             mt.e_c0x = scales.exp_for(scales.ln_bound(*coor_in))
             mt.e_c2x = scales.exp_for(scales.lin_bound(c0w, *coor_in, bias=self.coor_mlp[0].bias))
-        self._fused = bool(split and self.fused_tail)
+        self._fused = self._fused_cfg(split)
+        self._n_cross_batched = self.cross_layer_num if mt.wkv_cross else 0
         self._packed = (mt, (layers, tgt_layers), keep)
         self._packed_sig = sig
         # the pack kernels and copies above were enqueued on the CURRENT stream; any other stream (a concurrent lane,
@@ -215,7 +230,8 @@ class PointTransformer(nn.Module):
         if ops._stream() not in self._packed_streams:  # first forward of this stream since the weights were packed
             torch.cuda.current_stream(dev).wait_event(self._packed_event)
             self._packed_streams.add(ops._stream())
-        need = lib.scream_forward_workspace_bytes(batch.rows_src, batch.rows_total, batch.n_pairs, batch.max_chunks, int(self._fused))
+        need = lib.scream_forward_workspace_bytes(batch.rows_src, batch.rows_total, batch.n_pairs, batch.max_chunks, int(self._fused),
+                                                  self._n_cross_batched)
         # one scratch buffer per stream: concurrent lanes (scream_amd/lanes.py) run forwards of the same model side by side
         if self._ws is None:
             self._ws = {}

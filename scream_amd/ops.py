@@ -163,12 +163,16 @@ def pack_tail(Wm: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, split: Optio
 
 def kv_finalize_x3(partial: torch.Tensor, cloud_row0, cloud_len, row_base: int, cloud_begin: int, n_kv: int,
                    n_clouds: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """K^T V partials of gemm_qkv -> the per-cloud operand image of layer_tail ([n_clouds, kv_image_bytes] uint8)."""
+    """K^T V partials of gemm_qkv -> the per-cloud operand image of layer_tail ([n_clouds, kv_image_bytes] uint8).
+    partial [L, M/128, 8, 1056] (a batched key/value projection of L layers): returns [L, n_clouds, kv_image_bytes]."""
     lib = _lib.load()
+    L = partial.shape[0] if partial.dim() == 4 else 1
+    img = lib.scream_kv_image_bytes()
     if out is None:
-        out = torch.zeros(n_clouds, lib.scream_kv_image_bytes(), device=partial.device, dtype=torch.uint8)
+        out = torch.zeros((L, n_clouds, img) if partial.dim() == 4 else (n_clouds, img), device=partial.device, dtype=torch.uint8)
     check(lib.scream_kv_finalize_x3(_p(partial), _p(cloud_row0, torch.int32), _p(cloud_len, torch.int32), row_base,
-                                    cloud_begin, n_kv, _p(out, torch.uint8), _stream()), "scream_kv_finalize_x3")
+                                    cloud_begin, n_kv, _p(out, torch.uint8), L, partial[0].numel() if L > 1 else 0,
+                                    n_clouds * img if L > 1 else 0, _stream()), "scream_kv_finalize_x3")
     return out
 
 
@@ -195,7 +199,8 @@ def gemm_qkv(A: torch.Tensor, W, n_q: int, tile_cloud, cloud_row0, cloud_len, ro
     sp = isinstance(W, PackedW)  # packed operand planes -> the split kernel
     N = W.N if sp else W.shape[0]
     Q = torch.empty(M, n_q, device=A.device, dtype=torch.float32) if n_q else None
-    part = torch.empty(M // ROW_TILE, 8, KV_ELEMS, device=A.device, dtype=torch.float32)
+    L = (N - n_q) // 512  # key/value tile pairs: > 1 for a batched projection of several layers (split kernel, n_q == 0)
+    part = torch.empty((L, M // ROW_TILE, 8, KV_ELEMS) if L > 1 else (M // ROW_TILE, 8, KV_ELEMS), device=A.device, dtype=torch.float32)
     args = (_p(A), A.stride(0), W.data_ptr() if sp else _p(W), _p(Q), n_q, M, N, K, n_q,
             _p(tile_cloud, torch.int32), _p(cloud_row0, torch.int32), _p(cloud_len, torch.int32), row_base, _p(part))
     if sp:

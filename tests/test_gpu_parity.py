@@ -278,6 +278,54 @@ def test_fused_qkv_projection_and_kv_reduce_vs_oracle(kind):
     torch.testing.assert_close(kv2[1], kv[1], rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("split", ["h2", "x3"])
+def test_batched_key_value_projection_of_several_layers_equals_one_launch_per_layer(split):
+    """scream_gemm_qkv_split_f32 with N = 512 L, n_q == 0 (the cross stage's target side: the target features are frozen after
+    the stem, models/pointnet.py:53-57, so the L cross layers' key/value projections read the SAME rows): the partials of
+    layer l, at kv_partial + l (M/128) 8 1056, are bit for bit those of that layer's own N = 512 launch (same exponents), and
+    one scream_kv_finalize_x3 launch over all layers writes the same images as L launches."""
+    g = torch.Generator().manual_seed(17)
+    L, lens, row0, rows, base = 3, [300, 129, 700], [0, 384, 640], 1408, 256
+    x = torch.randn(base + rows, 256, generator=g)
+    Ws = [torch.randn(512, 256, generator=g) / 16 * (1 + l) for l in range(L)]
+    tiles = dev(torch.tensor([9] * 2 + [0] * 3 + [1] * 2 + [2] * 6, dtype=torch.int32))  # packed rows 256 .. are the three clouds
+    crow0, clen = dev(torch.tensor([base + r for r in row0], dtype=torch.int32)), dev(torch.tensor(lens, dtype=torch.int32))
+    SPL = SPLITS[split]
+    w_exp = scales.w_exp(torch.cat(Ws)) if split == "h2" else 0  # one exponent for the stacked matrix
+    a_exp = scales.exp_for(8.0)
+    xd = dev(x[base:].clamp(-8, 8))
+    _, part_all = ops.gemm_qkv(xd, ops.pack_w(dev(torch.cat(Ws)), SPL, w_exp), 0, tiles, crow0, clen, base, a_exp=a_exp)
+    assert part_all.shape == (L, rows // 128, 8, 1056)
+    img_all = ops.kv_finalize_x3(part_all, crow0, clen, base, 0, 3, 3)
+    for l in range(L):
+        _, part = ops.gemm_qkv(xd, ops.pack_w(dev(Ws[l]), SPL, w_exp), 0, tiles, crow0, clen, base, a_exp=a_exp)
+        assert torch.equal(part, part_all[l])
+        assert torch.equal(ops.kv_finalize_x3(part, crow0, clen, base, 0, 3, 3), img_all[l])
+
+
+@pytest.mark.parametrize("backend", ["h2", "x3"])
+def test_forward_batched_cross_key_values_equals_per_layer_launches(golden, backend):
+    """The forward projects the target features for all cross layers in one launch after the stem (net.batched_cross_kv,
+    default) instead of once per cross layer: same arithmetic.  bf16 x 3: bit for bit.  fp16 x 2: the stacked matrix carries ONE
+    power-of-two exponent (its largest element's) where each layer's own matrix carries its own, so the weights' second planes
+    round differently -- fp32-rounding-level agreement, and both reproduce the reference's outputs."""
+    g = golden("e2e")
+    for seed, ns, nc, n, m, explicit in g["cases"]:
+        if int(nc) == 0:
+            continue
+        center = dev(g["center_%d" % seed]) if explicit else None
+        outs = {}
+        for batched in (True, False):
+            net = build_net(int(seed), int(ns), int(nc), backend)
+            net.batched_cross_kv = batched
+            outs[batched] = net(dev(g["src_%d" % seed]), dev(g["tgt_%d" % seed]), center, 1.0, False, False, None)[0]
+            np.testing.assert_allclose(outs[batched].cpu().numpy(), g["out_%d" % seed], rtol=2e-4, atol=5e-5, err_msg="case seed=%d" % seed)
+        if backend == "x3":
+            assert torch.equal(outs[True], outs[False])
+        else:
+            torch.testing.assert_close(outs[True], outs[False], rtol=2e-5, atol=2e-5)
+
+
 # ----------------------------------------------------------------- A1-A6 whole forward pass
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_forward_vs_reference_golden(golden, backend):

@@ -39,10 +39,12 @@ def test_library_exports_every_declared_symbol():
 
 def test_host_side_argument_checks_need_no_gpu():
     lib = _lib.load()
-    unfused, fused = lib.scream_forward_workspace_bytes(128, 256, 1, 1, 0), lib.scream_forward_workspace_bytes(128, 256, 1, 1, 1)
+    unfused, fused = lib.scream_forward_workspace_bytes(128, 256, 1, 1, 0, 0), lib.scream_forward_workspace_bytes(128, 256, 1, 1, 1, 0)
     assert unfused > 256 * (256 * 5 + 1024) * 4  # x0, x1, q, att, m1 + hidden
     assert 256 * 256 * 3 * 4 < fused <= unfused - 256 * (256 * 2 + 1024) * 4  # the fused tail needs x0, x1, q only
-    assert lib.scream_forward_workspace_bytes(256, 128, 1, 1, 1) == -1  # rows_total < rows_src
+    assert lib.scream_forward_workspace_bytes(256, 128, 1, 1, 1, 0) == -1  # rows_total < rows_src
+    # six cross layers' target-side K^T V partials (one 128-row target tile x 8 heads x 1056 floats) and images side by side
+    assert lib.scream_forward_workspace_bytes(128, 256, 1, 1, 1, 6) - fused == 6 * (8 * 1056 * 4 + lib.scream_kv_image_bytes())
     # the split entry points validate `split` and the fp16 exponents on the host
     assert lib.scream_tail_image_bytes(2) == 72 * 32 * 1024 and lib.scream_tail_image_bytes(3) == 72 * 48 * 1024
     assert lib.scream_tail_image_bytes(4) == -1

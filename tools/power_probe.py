@@ -17,7 +17,7 @@ def sampler():
         except Exception as e:
             samples.append((time.time(), "ERR %r" % (e,)))
         time.sleep(0.05)
-th = threading.Thread(target=sampler); th.start()
+th = threading.Thread(target=sampler, daemon=True); th.start()  # (daemon: a traceback in the main thread must end the process)
 def burn(fn, secs, tag):
     t0 = time.time(); n = 0
     while time.time() - t0 < secs:

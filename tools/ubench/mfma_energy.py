@@ -34,7 +34,7 @@ def run():
             m = re.search(r"\((\d+)Mhz\),\d,\((\d+)Mhz\),\d,\((\d+)Mhz\),\d,.*,(\d+\.\d+)\s*$", o.strip().splitlines()[-1])
             if m: samples.append((time.time(), int(m.group(3)), float(m.group(4))))
             time.sleep(0.05)
-    th = threading.Thread(target=sampler); th.start()
+    th = threading.Thread(target=sampler, daemon=True); th.start()  # (daemon: a traceback in the main thread must end the process)
     iters = 2000
     flop = 256 * 4 * iters * 64 * 2.0 * 32 * 32 * 16  # blocks x waves x iterations x instruction(-pair)s x flops
     print("%-34s %9s %9s %9s %10s %12s %9s" % ("variant", "ms", "sclk MHz", "power W", "J/launch", "pJ/flop(dyn)", "PFLOP/s"))

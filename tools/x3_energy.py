@@ -23,7 +23,7 @@ def sampler():
         m = re.search(r"\((\d+)Mhz\),\d,\((\d+)Mhz\),\d,\((\d+)Mhz\),\d,.*,(\d+\.\d+)\s*$", out.strip().splitlines()[-1])
         if m: samples.append((time.time(), int(m.group(3)), float(m.group(4))))
         time.sleep(0.05)
-th = threading.Thread(target=sampler); th.start()
+th = threading.Thread(target=sampler, daemon=True); th.start()  # (daemon: a traceback in the main thread must end the process)
 tag = os.environ.get("X3_TAG", "")
 print("%-28s %9s %9s %9s %10s   (%s, M=%d; idle power ~296 W)" % ("variant", "ms", "sclk MHz", "power W", "J/launch", shape, M))
 for bits, label in x3_ablate.VARIANTS:
