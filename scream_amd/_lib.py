@@ -11,7 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscream_hip.so")
+# SCREAM_LIB=<path>: load that build instead (A/B runs of two builds on the same GPU box; never built automatically)
+LIB_PATH = os.environ.get("SCREAM_LIB") or os.path.join(_HERE, "libscream_hip.so")
 ABI_VERSION = 11
 
 c_f32p = C.POINTER(C.c_float)
@@ -98,7 +99,7 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if os.environ.get("SCREAM_NO_BUILD", "0") != "1":
+    if os.environ.get("SCREAM_NO_BUILD", "0") != "1" and not os.environ.get("SCREAM_LIB"):
         try:
             from . import build as _build
             _build.build()

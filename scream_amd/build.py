@@ -27,7 +27,10 @@ SOURCES = {
     "kabsch.hip": ["-ffp-contract=off"],
     "icp_grid.hip": ["-ffp-contract=off"],
 }
+# SCREAM_HIPCC_EXTRA="file.hip:-flag,-flag;file2.hip:-flag": extra compiler flags per source (experiments; empty in the product)
 EXTRA_DEFINES = {}
+for _item in filter(None, os.environ.get("SCREAM_HIPCC_EXTRA", "").split(";")):
+    EXTRA_DEFINES[_item.split(":")[0]] = _item.split(":", 1)[1].split(",")
 ASM_LOADS = ("gemm_split.hip", "tail_split.hip")  # verified after code generation, see verify_one
 
 
@@ -46,7 +49,11 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, out: str = None) -> str:
+    """out: write the library there instead of scream_amd/libscream_hip.so (experiment builds loaded with SCREAM_LIB=)."""
+    global LIB
+    if out:
+        LIB, force = out, True
     if not force and not _stale():
         return LIB
     hipcc = _hipcc()

@@ -195,7 +195,10 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_split_kernel(const float* __
         // loads in flight -- are issued between the two steps instead of in the post-barrier bubble.
         // tail: 0 steady, 1 = only D(kt+1) left to request, 2 = nothing.  Compile-time on purpose: with a conditional
         // load inside the loop hipcc stops counting and falls back to s_waitcnt vmcnt(0).
-        auto groups = [&](const char* wb, int s, const V (&pa)[NP], V (&fb)[2][NP]) {
+        // tr (compile time): the tile is computed TRANSPOSED -- the weight fragments are the MFMA's first operand, so lane =
+        // activation row, registers = output features: the fragment-major layout of a query tile, stored straight from the
+        // accumulators (below).  Same products in the same order either way.
+        auto groups = [&](auto tr, const char* wb, int s, const V (&pa)[NP], V (&fb)[2][NP]) __attribute__((always_inline)) {
 #pragma unroll
             for (int tn = 0; tn < 8; ++tn) {
                 const int cur = tn & 1, nxt = cur ^ 1;
@@ -209,7 +212,8 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_split_kernel(const float* __
                     acc[tn][0] += (float)pa[0][0] + (float)pa[NP - 1][1] + (float)fb[cur][0][0] + (float)fb[cur][NP - 1][0];
                     continue;
                 }
-                SP::template products<true>(acc[tn], pa, fb[cur], acc[tn]);
+                if (decltype(tr)::value) SP::template products<false>(acc[tn], fb[cur], pa, acc[tn]);
+                else SP::template products<true>(acc[tn], pa, fb[cur], acc[tn]);
                 // first MFMA, then the prefetch reads (one per plane), then the other MFMAs
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
@@ -228,7 +232,9 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_split_kernel(const float* __
                 split8<SP>(lo, hi, pa);
             }
         };
-        auto step = [&](auto tail, auto first, int kt, int stage, f32x4 (&ac)[4], f32x4 (&an1)[4], f32x4 (&an2)[4]) {
+        // (always_inline: with two copies of the k-loop in the kernel hipcc otherwise leaves `step` out of line in some
+        // instantiations -- operands passed through memory, behind the back of the hand-counted waits; the build's checker refused it)
+        auto step = [&](auto tr, auto tail, auto first, int kt, int stage, f32x4 (&ac)[4], f32x4 (&an1)[4], f32x4 (&an2)[4]) __attribute__((always_inline)) {
             constexpr int TAIL = decltype(tail)::value;
             constexpr bool FIRST = decltype(first)::value;
             // Everything but the four youngest operations (A(kt+1)) has landed: W k-tile kt is in LDS for every wave
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_split_kernel(const float* __
             V fb[2][NP];
 #pragma unroll
             for (int p = 0; p < NP; ++p) fb[0][p] = *reinterpret_cast<const V*>(wb + p * PLANE_BYTES + boff[0]);
-            groups(wb, 0, pa_s0, fb);
+            groups(tr, wb, 0, pa_s0, fb);
             STAMP(4 + kt * 4 + 2);
             if (TAIL <= 1 && !(X3_ABLATE & 2)) dma_w(n0, stage ^ 1, kt + 1);
             __builtin_amdgcn_sched_barrier(0);  // the counted waits rely on this issue order: D(kt+1), then A(kt+2)
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_split_kernel(const float* __
             asm volatile("" : "+v"(ac[3]));
             split_of(ac[2], ac[3], pa_s1);
             __builtin_amdgcn_sched_barrier(0);
-            groups(wb, 1, pa_s1, fb);
+            groups(tr, wb, 1, pa_s1, fb);
             STAMP(4 + kt * 4 + 3);
             if (TAIL <= 1 && !late) {  // A(kt+1) is older than what was requested above: wait for it alone, split its first half
                 if (TAIL == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | (WPW + 4)); else __builtin_amdgcn_s_waitcnt(0x0F70 | WPW);  // vmcnt only
@@ -276,20 +282,33 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_split_kernel(const float* __
         constexpr std::integral_constant<int, 2> tail2{};
         constexpr std::integral_constant<bool, true> first{};
         constexpr std::integral_constant<bool, false> later{};
-        if (KT > 2) {  // (KT - 2) % 3 == 0 (host check); KT is even, so stage = kt & 1
-            step(steady, first, 0, 0, a0, a1, a2);
-            step(steady, later, 1, 1, a1, a2, a0);
-            step(steady, later, 2, 0, a2, a0, a1);
-            for (int kt = 3; kt < KT - 2; kt += 3) {
-                step(steady, later, kt, kt & 1, a0, a1, a2);
-                step(steady, later, kt + 1, (kt + 1) & 1, a1, a2, a0);
-                step(steady, later, kt + 2, kt & 1, a2, a0, a1);
+        auto k_loop = [&](auto tr) __attribute__((always_inline)) {
+            if (KT > 2) {  // (KT - 2) % 3 == 0 (host check); KT is even, so stage = kt & 1
+                step(tr, steady, first, 0, 0, a0, a1, a2);
+                step(tr, steady, later, 1, 1, a1, a2, a0);
+                step(tr, steady, later, 2, 0, a2, a0, a1);
+                for (int kt = 3; kt < KT - 2; kt += 3) {
+                    step(tr, steady, later, kt, kt & 1, a0, a1, a2);
+                    step(tr, steady, later, kt + 1, (kt + 1) & 1, a1, a2, a0);
+                    step(tr, steady, later, kt + 2, kt & 1, a2, a0, a1);
+                }
+                step(tr, tail1, later, KT - 2, 0, a0, a1, a2);
+            } else {
+                step(tr, tail1, first, 0, 0, a0, a1, a2);
             }
-            step(tail1, later, KT - 2, 0, a0, a1, a2);
+            step(tr, tail2, later, KT - 1, 1, a1, a2, a2);
+        };
+        // a query tile whose result goes out fragment-major (SCREAM_LAYOUT_C_FRAG: n_act == ldc == 256, so it is the tile at
+        // column 0) is computed transposed; uniform per tile.  SplitH2 only: the bf16 x 3 instantiations stay the round-2 code
+        // (a second copy of their k-loop costs them spill stores inside the tile loop, which tests/test_host_cpu.py forbids)
+        constexpr bool CAN_TR = SP::SCALED && (EPI == SCREAM_EPI_ELU1 || EPI == SCREAM_EPI_QKV);
+        const bool tr_cur = CAN_TR && ep.c_frag && n0 < ep.n_act;
+        if constexpr (CAN_TR) {
+            if (tr_cur) k_loop(std::integral_constant<bool, true>{});
+            else k_loop(std::integral_constant<bool, false>{});
         } else {
-            step(tail1, first, 0, 0, a0, a1, a2);
+            k_loop(std::integral_constant<bool, false>{});
         }
-        step(tail2, later, KT - 1, 1, a1, a2, a2);
 
         STAMP(1);
         // next output tile: its first k-tile lands under the epilogue (the slabs have their own LDS region)
@@ -318,7 +337,30 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_split_kernel(const float* __
 #pragma unroll
                 for (int tn = 0; tn < 8; ++tn) acc[tn] *= c_scale;
             }
-            gemm_epilogue<EPI, XWAVES>(acc, slabs, wave, lane, tid, rows_cur, m0_cur, n0_cur, ep, C, ldc);
+            if (CAN_TR && tr_cur) {
+                // Q' = elu(q) + 1, fragment-major (SCREAM_ACT_FRAG), straight from the transposed accumulators: register
+                // 4a + b of lane (r, half) in tile tn is feature 32 tn + 8 a + 4 half + b of row r, i.e. float
+                // ((tn * 4 + a) * 64 + lane) * 4 + b of the wave's 32-row group -- one contiguous 1 KiB per store instruction,
+                // no LDS slab, no transposition (the slab epilogue was a third of this kernel's time on query tiles,
+                // profiles/r03_gemm_ablation_h2.txt)
+                if (rows_cur) {
+                    float* cg = C + (m0_cur + wave * 32) * 256 + lane * 4;
+#pragma unroll
+                    for (int tn = 0; tn < 8; ++tn)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            f32x4 o;
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const float x = acc[tn][4 * a + b];
+                                o[b] = x > 0.f ? x + 1.0f : expf(x);  // elu(x) + 1 == exp(x), x <= 0
+                            }
+                            *reinterpret_cast<f32x4*>(cg + (tn * 4 + a) * 256) = o;
+                        }
+                }
+            } else {
+                gemm_epilogue<EPI, XWAVES>(acc, slabs, wave, lane, tid, rows_cur, m0_cur, n0_cur, ep, C, ldc);
+            }
         }
         STAMP(2);
         if (!has_next) break;

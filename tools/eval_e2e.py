@@ -1,29 +1,96 @@
 #!/usr/bin/env python3
-"""End-to-end evaluate_loader throughput on pre-generated synthetic 3DMatch-like items (host work included:
-H2D copies, packing, metric rows, RMSE) -- compare with bench.py's device-resident pairs/s."""
-import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from scream_amd.data import SyntheticPairs
-from scream_amd.evaluate import evaluate_loader
-from scream_amd.model import PointTransformer
-from scream_amd.synthetic import make_state_dict
-import multiprocessing as mp
+"""End-to-end evaluate_loader throughput through the Python boundary -- host packing, H2D copies, A1-A10 (+ GPU ICP), metric
+rows, RMSE, aggregation all included -- to set beside bench.py's device-resident pairs/s.  Three legs, each >= 2 048 pairs:
 
-def gen(i):
-    return SyntheticPairs("3dmatch", 1, seed0=i)[0]
+  1. in-memory items, icp=None          (pre-ICP metrics)
+  2. in-memory items, icp="gpu"         (the reference's default: every pose refined, evaluate_3d_match.py:106-119)
+  3. FROM FILES: a split directory written in the reference's on-disk format (process_3d_match.py:38-40,199-200; float64
+     src%d.npy / tgt%d.npy, T%d.npy, info/idx%d.npy, info/covariance%d.npy, info/scene_names.txt) read back through
+     PairFileDataset + evaluate_loader(num_workers=k) (np.load + the per-item normalisation of
+     datasets/three_d_match.py:228-242 in worker processes, pinned batches), for several k: which k sustains >= 95 % of leg 2.
+
+The synthetic pairs are `--distinct` (default 256) seeded 3DMatch-like pairs, each visited n / distinct times (the files stay in
+the page cache, as a test split of 1 253 small pairs does on any host).  usage: eval_e2e.py [n_pairs] [--distinct D] [--gen-procs P]"""
+import argparse, os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+
+def gen_raw(i):
+    """Raw (un-normalised, float64) pair + metadata, as process_3d_match.py would write it."""
+    from scream_amd import synthetic
+    return synthetic.make_3dmatch_pair(i, "3dmatch")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("n", nargs="?", type=int, default=2048)
+    ap.add_argument("--distinct", type=int, default=256)
+    ap.add_argument("--gen-procs", type=int, default=14, help="1 = generate in-process (e.g. under rocprofv3)")
+    ap.add_argument("--workers", default="0,2,4,8,12")
+    args = ap.parse_args()
+    D = min(args.distinct, args.n)
+    if args.gen_procs > 1:  # before anything touches the GPU
+        import multiprocessing as mp
+        with mp.get_context("spawn").Pool(args.gen_procs) as pool:
+            raw = pool.map(gen_raw, range(D))
+    else:
+        raw = [gen_raw(i) for i in range(D)]
+
+    import torch
+    from scream_amd.data import SCENE_DIR_TO_IDX, PairFileDataset, normalize_pair
+    from scream_amd.evaluate import evaluate_loader
+    from scream_amd.model import PointTransformer
+    from scream_amd.synthetic import make_state_dict
+    scene_dirs = {v: k for k, v in SCENE_DIR_TO_IDX.items()}
+
+    def item(r):
+        src, tgt, T, idx, cov, scene = r
+        s_n, t_n, rot, trans, s, c = normalize_pair(src, tgt, T)
+        return (s_n, t_n, rot, trans, s, torch.LongTensor(idx), torch.Tensor(cov), c, scene)
+    items = [item(r) for r in raw]
+
+    class Mem(torch.utils.data.Dataset):
+        def __len__(self): return args.n
+        def __getitem__(self, i): return items[i % D]
+
+    net = PointTransformer(256, 6, 6); net.load_state_dict(make_state_dict(0, 256, 6, 6)); net = net.to("cuda:0").eval()
+    print("evaluate_loader end to end, %d pairs per leg (%d distinct synthetic 3DMatch-like pairs, mean %.0f + %.0f points), batch 32, gemm_backend %s"
+          % (args.n, D, np.mean([r[0].shape[0] for r in raw]), np.mean([r[1].shape[0] for r in raw]), net.gemm_backend), flush=True)
+    evaluate_loader(net, torch.utils.data.Subset(Mem(), range(64)), batch_pairs=32, verbose=False)  # warm-up
+
+    def leg(tag, ds, **kw):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = evaluate_loader(net, ds, batch_pairs=32, verbose=False, **kw)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print("%-46s %5d pairs in %6.2f s -> %7.1f pairs/s   (loss, rre, rte, rr) = %s" % (tag, len(ds), dt, len(ds) / dt, tuple(round(float(v), 4) for v in out)), flush=True)
+        return len(ds) / dt, out
+    leg("1. in-memory, icp=None", Mem(), icp=None)
+    mem_rate, mem_out = leg("2. in-memory, icp='gpu' (reference default)", Mem(), icp="gpu")
+
+    with tempfile.TemporaryDirectory() as root:  # the reference's on-disk layout, process_3d_match.py:38-40,199-200
+        os.makedirs(os.path.join(root, "info"))
+        for i, (src, tgt, T, idx, cov, scene) in enumerate(raw):
+            np.save(os.path.join(root, "src%d.npy" % i), np.asarray(src, dtype=np.float64))
+            np.save(os.path.join(root, "tgt%d.npy" % i), np.asarray(tgt, dtype=np.float64))
+            np.save(os.path.join(root, "T%d.npy" % i), np.asarray(T, dtype=np.float64))
+            np.save(os.path.join(root, "info", "idx%d.npy" % i), np.asarray(idx))
+            np.save(os.path.join(root, "info", "covariance%d.npy" % i), np.asarray(cov))
+        with open(os.path.join(root, "info", "scene_names.txt"), "w") as f:
+            f.write("\n".join(scene_dirs[r[5]] for r in raw) + "\n")
+        files = PairFileDataset(root)
+
+        class Cycled(torch.utils.data.Dataset):  # every file n / D times
+            def __len__(self): return args.n
+            def __getitem__(self, i): return files[i % D]
+        best = None
+        for k in [int(v) for v in args.workers.split(",")]:
+            rate, out = leg("3. from files, icp='gpu', num_workers=%d" % k, Cycled(), icp="gpu", num_workers=k)
+            assert all(abs(float(a) - float(b)) < 1e-9 for a, b in zip(out, mem_out)), "from-files results differ from in-memory"
+            if best is None and rate >= 0.95 * mem_rate:
+                best = k
+        print("smallest num_workers that sustains >= 95 %% of the in-memory rate (%.1f pairs/s): %s" % (mem_rate, best), flush=True)
+
 
 if __name__ == "__main__":
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-    with mp.get_context("spawn").Pool(14) as pool:
-        items = pool.map(gen, range(n))
-    class Mem(torch.utils.data.Dataset):
-        def __len__(self): return len(items)
-        def __getitem__(self, i): return items[i]
-    net = PointTransformer(256, 6, 6); net.load_state_dict(make_state_dict(0, 256, 6, 6)); net = net.to("cuda:0").eval()
-    evaluate_loader(net, Mem(), batch_pairs=32, verbose=False)  # warm-up
-    for icp in (None, "gpu"):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        out = evaluate_loader(net, Mem(), batch_pairs=32, verbose=False, icp=icp)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print("evaluate_loader icp=%s: %d pairs in %.2f s -> %.1f pairs/s   (loss, rre, rte, rr) = %s" % (icp, n, dt, n / dt, tuple(round(float(v), 4) for v in out)))
+    main()
