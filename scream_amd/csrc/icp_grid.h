@@ -7,6 +7,55 @@ constexpr int ICP_GRID_CELLS = 1 << 17;  // cells per pair (50^3 fits: a 5 m clo
 
 namespace scream_internal {
 
+struct GridParam {  // per pair
+    float ox, oy, oz, inv_h;
+    int32_t nx, ny, nz, ncell;
+};
+
+#ifdef __HIPCC__
+typedef float icp_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int cell_coord(float x, float o, float inv_h, int n) {
+    const int c = (int)floorf((x - o) * inv_h);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+// Nearest target of ONE query point within the radius (thresh = radius^2), over the nine x-runs of the 27 cells around it:
+// the same explicitly rounded distance as nn_search_kernel with s = 1, ties to the lowest ORIGINAL target index.
+// st / sp / si: the pair's cell starts, sorted records {b, |b|^2} and original indices.  Shared by grid_search_kernel
+// (one launch per iteration).
+__device__ __forceinline__ void grid_search_point(const GridParam& g, const int32_t* __restrict__ st, const float* __restrict__ sp,
+                                                  const int32_t* __restrict__ si, float ax, float ay, float az, float thresh,
+                                                  int32_t& idx_out, float& d_out, uint8_t& valid_out) {
+    const float sa = __fadd_rn(__fadd_rn(__fmul_rn(ax, ax), __fmul_rn(ay, ay)), __fmul_rn(az, az));
+    const int cx = cell_coord(ax, g.ox, g.inv_h, g.nx), cy = cell_coord(ay, g.oy, g.inv_h, g.ny), cz = cell_coord(az, g.oz, g.inv_h, g.nz);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+    float best = __builtin_inff();
+    int bi = 0x7fffffff;
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.nz - 1); ++z)
+        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.ny - 1); ++y) {
+            const int c0 = (z * g.ny + y) * g.nx;
+            const int jb = st[c0 + x0], je = st[c0 + x1 + 1];
+            for (int j = jb; j < je; ++j) {
+                const icp_f32x4 b = *reinterpret_cast<const icp_f32x4*>(sp + (int64_t)j * 4);
+                float dot = __fmul_rn(ax, b[0]);
+                dot = __fmaf_rn(ay, b[1], dot);
+                dot = __fmaf_rn(az, b[2], dot);
+                const float d = __fadd_rn(__fmaf_rn(-2.0f, dot, sa), b[3]);
+                const int o = si[j];
+                if (d < best || (d == best && o < bi)) {
+                    best = d;
+                    bi = o;
+                }
+            }
+        }
+    const bool ok = best < thresh;
+    idx_out = ok ? bi : -1;
+    d_out = ok ? best : __builtin_inff();
+    valid_out = ok ? 1 : 0;
+}
+#endif
+
 struct IcpGrid {
     const void* params;        // per pair: origin, 1 / cell edge, dimensions
     const int32_t* start;      // [n_pairs][ICP_GRID_CELLS + 1] first sorted position of every cell
@@ -17,8 +66,10 @@ struct IcpGrid {
 int64_t icp_grid_workspace_floats(int64_t ref_rows_total, int32_t n_pairs);
 int icp_grid_build(const float* ref_m, const float* ref_prep, const int32_t* r_row0, const int32_t* r_len, int32_t n_pairs,
                    int32_t max_r_len, int64_t ref_rows_total, float radius, float* work, IcpGrid* out, hipStream_t st);
-int icp_grid_search(const IcpGrid& g, const float* query, const int32_t* q_row0, const int32_t* q_len, const int32_t* r_row0,
-                    int32_t n_pairs, int32_t max_q_len, float thresh, int32_t* idx, float* dmin, uint8_t* valid, hipStream_t st);
+// q = T[pair] . src (written out for the Kabsch update's gather), then the thresholded nearest target of q on the grid
+int icp_grid_search(const IcpGrid& g, const float* src, const float* T, float* q, const int32_t* q_row0, const int32_t* q_len,
+                    const int32_t* r_row0, int32_t n_pairs, int32_t max_q_len, float thresh, int32_t* idx, float* dmin,
+                    uint8_t* valid, hipStream_t st);
 // nn_search.hip: ref_prep[row] = {b / s, |b / s|^2} (the brute-force search's own preparation) and the padding fill
 int nn_prepare_targets(const float* ref, const int32_t* r_row0, const int32_t* r_len, const float* s, int32_t n_pairs,
                        int32_t max_r_len, float* ref_prep, hipStream_t st);

@@ -23,15 +23,8 @@
 
 namespace {
 
-struct GridParam {  // per pair
-    float ox, oy, oz, inv_h;
-    int32_t nx, ny, nz, ncell;
-};
-
-__device__ __forceinline__ int cell_coord(float x, float o, float inv_h, int n) {
-    const int c = (int)floorf((x - o) * inv_h);
-    return c < 0 ? 0 : (c >= n ? n - 1 : c);
-}
+using scream_internal::GridParam;
+using scream_internal::cell_coord;
 
 // grid n_pairs, block 256: bounding box of the pair's targets (metric coordinates) and the grid over it
 __global__ __launch_bounds__(256) void grid_params_kernel(const float* __restrict__ ref, const int32_t* __restrict__ r_row0,
@@ -142,8 +135,11 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restri
     sorted_idx[r0 + pos] = i;
 }
 
-// grid (ceil(max_q_len / 256), n_pairs): one query per thread; same rounding sequence as nn_search_kernel with s = 1
-__global__ __launch_bounds__(256) void grid_search_kernel(const float* __restrict__ query, const int32_t* __restrict__ q_row0,
+// grid (ceil(max_q_len / 256), n_pairs): one query per thread -- the source point under the pair's current transform (the
+// arithmetic of icp_transform_kernel, kabsch.hip; written to q for the Kabsch update) -- same rounding sequence as
+// nn_search_kernel with s = 1
+__global__ __launch_bounds__(256) void grid_search_kernel(const float* __restrict__ src, const float* __restrict__ T,
+                                                         float* __restrict__ query, const int32_t* __restrict__ q_row0,
                                                          const int32_t* __restrict__ q_len, const int32_t* __restrict__ r_row0,
                                                          const GridParam* __restrict__ gp, const int32_t* __restrict__ start,
                                                          const float* __restrict__ sorted_prep,
@@ -152,38 +148,21 @@ __global__ __launch_bounds__(256) void grid_search_kernel(const float* __restric
                                                          uint8_t* __restrict__ valid) {
     const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= q_len[p]) return;
-    const GridParam g = gp[p];
     const int64_t row = (int64_t)q_row0[p] + i;
-    const float ax = query[row * 3 + 0], ay = query[row * 3 + 1], az = query[row * 3 + 2];
-    const float sa = __fadd_rn(__fadd_rn(__fmul_rn(ax, ax), __fmul_rn(ay, ay)), __fmul_rn(az, az));
-    const int cx = cell_coord(ax, g.ox, g.inv_h, g.nx), cy = cell_coord(ay, g.oy, g.inv_h, g.ny), cz = cell_coord(az, g.oz, g.inv_h, g.nz);
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-    const int32_t* st = start + (int64_t)p * (ICP_GRID_CELLS + 1);
-    const float* sp = sorted_prep + (int64_t)r_row0[p] * 4;
-    const int32_t* si = sorted_idx + r_row0[p];
-    float best = __builtin_inff();
-    int bi = 0x7fffffff;
-    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.nz - 1); ++z)
-        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.ny - 1); ++y) {
-            const int c0 = (z * g.ny + y) * g.nx;
-            const int jb = st[c0 + x0], je = st[c0 + x1 + 1];
-            for (int j = jb; j < je; ++j) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(sp + (int64_t)j * 4);
-                float dot = __fmul_rn(ax, b[0]);
-                dot = __fmaf_rn(ay, b[1], dot);
-                dot = __fmaf_rn(az, b[2], dot);
-                const float d = __fadd_rn(__fmaf_rn(-2.0f, dot, sa), b[3]);
-                const int o = si[j];
-                if (d < best || (d == best && o < bi)) {
-                    best = d;
-                    bi = o;
-                }
-            }
-        }
-    const bool ok = best < thresh;
-    idx[row] = ok ? bi : -1;
-    dmin[row] = ok ? best : __builtin_inff();
-    valid[row] = ok ? 1 : 0;
+    const float* t = T + p * 16;
+    const float x = src[row * 3 + 0], y = src[row * 3 + 1], z = src[row * 3 + 2];
+    const float ax = t[0] * x + t[1] * y + t[2] * z + t[3], ay = t[4] * x + t[5] * y + t[6] * z + t[7], az = t[8] * x + t[9] * y + t[10] * z + t[11];
+    query[row * 3 + 0] = ax;
+    query[row * 3 + 1] = ay;
+    query[row * 3 + 2] = az;
+    int32_t bi;
+    float best;
+    uint8_t ok;
+    scream_internal::grid_search_point(gp[p], start + (int64_t)p * (ICP_GRID_CELLS + 1), sorted_prep + (int64_t)r_row0[p] * 4,
+                                       sorted_idx + r_row0[p], ax, ay, az, thresh, bi, best, ok);
+    idx[row] = bi;
+    dmin[row] = best;
+    valid[row] = ok;
 }
 
 }  // namespace
@@ -225,11 +204,12 @@ int icp_grid_build(const float* ref_m, const float* ref_prep, const int32_t* r_r
     return 0;
 }
 
-int icp_grid_search(const IcpGrid& g, const float* query, const int32_t* q_row0, const int32_t* q_len, const int32_t* r_row0,
-                    int32_t n_pairs, int32_t max_q_len, float thresh, int32_t* idx, float* dmin, uint8_t* valid, hipStream_t st) {
+int icp_grid_search(const IcpGrid& g, const float* src, const float* T, float* q, const int32_t* q_row0, const int32_t* q_len,
+                    const int32_t* r_row0, int32_t n_pairs, int32_t max_q_len, float thresh, int32_t* idx, float* dmin,
+                    uint8_t* valid, hipStream_t st) {
     if (max_q_len <= 0 || n_pairs <= 0) return 0;
     grid_search_kernel<<<dim3((max_q_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(
-        query, q_row0, q_len, r_row0, reinterpret_cast<const GridParam*>(g.params), g.start, g.sorted_prep, g.sorted_idx, thresh, idx,
+        src, T, q, q_row0, q_len, r_row0, reinterpret_cast<const GridParam*>(g.params), g.start, g.sorted_prep, g.sorted_idx, thresh, idx,
         dmin, valid);
     SCREAM_LAUNCH_CHECK();
     return 0;

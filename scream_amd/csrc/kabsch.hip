@@ -159,9 +159,13 @@ __device__ void solve_pose(const double H[3][3], const float cA[3], const float 
     T[15] = 1.f;
 }
 
-// Workgroup-wide sum of NV doubles per thread; result broadcast to every thread.  256 threads.
-template <int NV>
-__device__ void block_sum(double (&v)[NV], double* red /* [4][NV] */) {
+// Workgroup-wide sum of NV doubles per thread; result broadcast to every thread.  NT threads (256: the A9 solve; 1024:
+// the ICP update), combined in a fixed order -- waves pairwise, then groups of four -- so the sum depends on NT and on
+// nothing else.
+template <int NV, int NT = 256>
+__device__ void block_sum(double (&v)[NV], double* red /* [NT / 64][NV] */) {
+    constexpr int NW = NT / 64;
+    static_assert(NW == 4 || NW == 16, "");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = wave_sum_f64(v[k]);
@@ -172,7 +176,13 @@ __device__ void block_sum(double (&v)[NV], double* red /* [4][NV] */) {
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = (red[0 * NV + k] + red[1 * NV + k]) + (red[2 * NV + k] + red[3 * NV + k]);
+    for (int k = 0; k < NV; ++k) {
+        double q4[NW / 4];
+#pragma unroll
+        for (int g = 0; g < NW / 4; ++g)
+            q4[g] = (red[(4 * g + 0) * NV + k] + red[(4 * g + 1) * NV + k]) + (red[(4 * g + 2) * NV + k] + red[(4 * g + 3) * NV + k]);
+        v[k] = NW == 4 ? q4[0] : (q4[0] + q4[1 % (NW / 4)]) + (q4[2 % (NW / 4)] + q4[3 % (NW / 4)]);
+    }
 }
 
 struct CorrFetch {  // evaluate_3d_match.py:96-101
@@ -218,13 +228,13 @@ struct DenseFetch {  // utils.py:138-151
     }
 };
 
-template <class Fetch>
+template <class Fetch, int NT = 256>
 __device__ void kabsch_block(const Fetch& f, float* T_out, int32_t* n_corr_out) {
-    __shared__ double red[4 * 9];
+    __shared__ double red[NT / 64 * 9];
     double acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.0;
-    for (int i = threadIdx.x; i < f.n; i += 256) {
+    for (int i = threadIdx.x; i < f.n; i += NT) {
         float a[3], b[3], w;
         if (f.get(i, a, b, w)) {
             acc[0] += (double)(a[0] * w);
@@ -237,7 +247,7 @@ __device__ void kabsch_block(const Fetch& f, float* T_out, int32_t* n_corr_out) 
             acc[7] += 1.0;
         }
     }
-    block_sum<9>(acc, red);
+    block_sum<9, NT>(acc, red);
     const float denom = (float)acc[6] + 1e-6f;  // utils.py:155-158
     const float cA[3] = {(float)acc[0] / denom, (float)acc[1] / denom, (float)acc[2] / denom};
     const float cB[3] = {(float)acc[3] / denom, (float)acc[4] / denom, (float)acc[5] / denom};
@@ -246,7 +256,7 @@ __device__ void kabsch_block(const Fetch& f, float* T_out, int32_t* n_corr_out) 
     double h[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) h[k] = 0.0;
-    for (int i = threadIdx.x; i < f.n; i += 256) {
+    for (int i = threadIdx.x; i < f.n; i += NT) {
         float a[3], b[3], w;
         if (f.get(i, a, b, w)) {
             const float am[3] = {a[0] - cA[0], a[1] - cA[1], a[2] - cA[2]};
@@ -257,7 +267,7 @@ __device__ void kabsch_block(const Fetch& f, float* T_out, int32_t* n_corr_out) 
                 for (int c = 0; c < 3; ++c) h[r * 3 + c] += (double)am[r] * (double)bm[c];
         }
     }
-    block_sum<9>(h, red);
+    block_sum<9, NT>(h, red);
     if (threadIdx.x < 64) {  // wave 0, every lane redundantly (wave-uniform data)
         double H[3][3];
 #pragma unroll
@@ -365,32 +375,31 @@ struct IcpState {  // per pair
     int32_t done, iters;
 };
 
-// One workgroup per pair: fitness / inlier RMSE of the current correspondences, convergence test, and (if the
-// pair goes on) the Kabsch update composed into T.  q = transformed source, idx/valid/dmin from the search.
-__global__ __launch_bounds__(256) void icp_update_kernel(const float* __restrict__ q, const float* __restrict__ ref,
-                                                        const int32_t* __restrict__ src_row0,
-                                                        const int32_t* __restrict__ src_len,
-                                                        const int32_t* __restrict__ ref_row0,
-                                                        const int32_t* __restrict__ idx,
-                                                        const uint8_t* __restrict__ valid,
-                                                        const float* __restrict__ dmin, int iter, int max_iter,
-                                                        float rel_fitness, float rel_rmse, float* __restrict__ T,
-                                                        IcpState* __restrict__ state, int32_t* __restrict__ act_len,
-                                                        float* __restrict__ fit_rmse_out,
-                                                        int32_t* __restrict__ iters_out) {
-    __shared__ double red2[4 * 2];
-    const int p = blockIdx.x;
-    IcpState st = state[p];
-    if (st.done) return;  // block-uniform
+constexpr int ICP_NT = 1024;  // threads of an ICP workgroup (one workgroup per pair)
+
+// One workgroup (ICP_NT threads) per pair: fitness / inlier RMSE of the current correspondences, convergence test, and (if
+// the pair goes on) the Kabsch update composed into T.  q = transformed source, idx/valid/dmin from the search.  Returns
+// (block-uniform) whether the pair has stopped.  1024 threads since round 3 (256 before: three latency-bound passes of
+// dependent gathers over ~5 k points took 43 us per iteration, more than the search it follows).
+// (Tried in round 3 and dropped: the whole loop of a pair inside one workgroup, profiles/r03_icp_one_workgroup_loop.txt.)
+// (no __restrict__ on q / idx / valid / dmin / T / state: the one-launch loop writes them between calls)
+__device__ bool icp_update_block(int p, const float* q, const float* __restrict__ ref,
+                                 const int32_t* __restrict__ src_row0, const int32_t* __restrict__ src_len,
+                                 const int32_t* __restrict__ ref_row0, const int32_t* idx,
+                                 const uint8_t* valid, const float* dmin, int iter, int max_iter,
+                                 float rel_fitness, float rel_rmse, float* T, IcpState* state,
+                                 int32_t* act_len, float* fit_rmse_out, int32_t* iters_out) {
+    __shared__ double red2[ICP_NT / 64 * 2];
+    const IcpState st = state[p];
     const int n = src_len[p];
     const int64_t r0 = src_row0[p];
     double acc[2] = {0.0, 0.0};
-    for (int i = threadIdx.x; i < n; i += 256)
+    for (int i = threadIdx.x; i < n; i += ICP_NT)
         if (valid[r0 + i]) {
             acc[0] += 1.0;
             acc[1] += (double)dmin[r0 + i];
         }
-    block_sum<2>(acc, red2);
+    block_sum<2, ICP_NT>(acc, red2);
     const float fitness = n > 0 ? (float)(acc[0] / n) : 0.f;
     const float rmse = acc[0] > 0 ? (float)sqrt(acc[1] / acc[0]) : 0.f;
     const bool converged = iter > 0 && fabsf(st.fitness - fitness) < rel_fitness && fabsf(st.rmse - rmse) < rel_rmse;
@@ -406,21 +415,37 @@ __global__ __launch_bounds__(256) void icp_update_kernel(const float* __restrict
         if (iters_out) iters_out[p] = iter;  // number of updates applied
         if (stop) act_len[p] = 0;            // a finished pair costs no further transform / search work
     }
-    if (stop) return;
-    float dT[16];
+    if (stop) return true;
+    float v = 0.f;
     CorrFetch f{q, ref, idx, valid, r0, ref_row0[p], 1.0f, 0.f, 0.f, 0.f, n};
     __shared__ float dT_sh[16];
-    kabsch_block(f, dT_sh, nullptr);
+    kabsch_block<CorrFetch, ICP_NT>(f, dT_sh, nullptr);
     __syncthreads();
     if (threadIdx.x < 16) {  // T <- dT . T
         const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
-        float v = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) v += dT_sh[i * 4 + k] * T[p * 16 + k * 4 + j];
-        dT[0] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 16) T[p * 16 + threadIdx.x] = dT[0];
+    if (threadIdx.x < 16) T[p * 16 + threadIdx.x] = v;
+    return false;
+}
+
+__global__ __launch_bounds__(ICP_NT) void icp_update_kernel(const float* __restrict__ q, const float* __restrict__ ref,
+                                                           const int32_t* __restrict__ src_row0,
+                                                           const int32_t* __restrict__ src_len,
+                                                           const int32_t* __restrict__ ref_row0,
+                                                           const int32_t* __restrict__ idx,
+                                                           const uint8_t* __restrict__ valid,
+                                                           const float* __restrict__ dmin, int iter, int max_iter,
+                                                           float rel_fitness, float rel_rmse, float* __restrict__ T,
+                                                           IcpState* __restrict__ state, int32_t* __restrict__ act_len,
+                                                           float* __restrict__ fit_rmse_out,
+                                                           int32_t* __restrict__ iters_out) {
+    const int p = blockIdx.x;
+    if (state[p].done) return;  // block-uniform
+    icp_update_block(p, q, ref, src_row0, src_len, ref_row0, idx, valid, dmin, iter, max_iter, rel_fitness, rel_rmse, T, state,
+                     act_len, fit_rmse_out, iters_out);
 }
 
 }  // namespace
@@ -517,16 +542,19 @@ extern "C" int scream_icp_p2p(const float* src, const float* ref, const int32_t*
     }
     std::vector<IcpState> host_state;
     for (int it = 0; it <= max_iter; ++it) {
-        if (max_src_len > 0)
-            icp_transform_kernel<<<dim3((max_src_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(src_m, src_row0, act_len, T, q);
-        SCREAM_LAUNCH_CHECK();
-        int rc = brute ? scream_nn_search(q, ref_m, src_row0, act_len, ref_row0, ref_len, ones, n_pairs, max_src_len, max_ref_len,
-                                          src_rows_total, ref_rows_total, max_corr_dist * max_corr_dist, ref_prep, keys, idx, dmin,
-                                          valid, stream)
-                       : scream_internal::icp_grid_search(grid, q, src_row0, act_len, ref_row0, n_pairs, max_src_len,
-                                                          max_corr_dist * max_corr_dist, idx, dmin, valid, st);
+        int rc;
+        if (brute) {  // SCREAM_ICP_BRUTE=1, the yardstick of the tests: transform, then the brute-force search of nn_search.hip
+            if (max_src_len > 0)
+                icp_transform_kernel<<<dim3((max_src_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(src_m, src_row0, act_len, T, q);
+            SCREAM_LAUNCH_CHECK();
+            rc = scream_nn_search(q, ref_m, src_row0, act_len, ref_row0, ref_len, ones, n_pairs, max_src_len, max_ref_len,
+                                  src_rows_total, ref_rows_total, max_corr_dist * max_corr_dist, ref_prep, keys, idx, dmin, valid, stream);
+        } else {      // two launches per iteration: the transform rides in the grid search (same arithmetic, one launch fewer)
+            rc = scream_internal::icp_grid_search(grid, src_m, T, q, src_row0, act_len, ref_row0, n_pairs, max_src_len,
+                                                  max_corr_dist * max_corr_dist, idx, dmin, valid, st);
+        }
         if (rc != 0) return rc;
-        icp_update_kernel<<<dim3(n_pairs), dim3(256), 0, st>>>(q, ref_m, src_row0, src_len, ref_row0, idx, valid, dmin, it,
+        icp_update_kernel<<<dim3(n_pairs), dim3(ICP_NT), 0, st>>>(q, ref_m, src_row0, src_len, ref_row0, idx, valid, dmin, it,
                                                                max_iter, rel_fitness, rel_rmse, T, state, act_len,
                                                                fitness_rmse, iters);
         SCREAM_LAUNCH_CHECK();

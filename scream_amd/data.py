@@ -85,6 +85,40 @@ class SyntheticPairs(Dataset):
         return (src_n, tgt_n, rot, trans, s, torch.LongTensor(idx), torch.Tensor(cov), c, scene)
 
 
-def collate_pairs(items: Sequence[tuple]) -> List[tuple]:
-    """Var-len pairs cannot be stacked: a batch is simply the list of 9-tuples."""
-    return list(items)
+_PACKED = "scream-packed-batch-v1"
+
+
+def collate_pairs(items: Sequence[tuple]):
+    """Var-len pairs cannot be stacked: in the main process a batch is simply the list of 9-tuples.  In a DataLoader WORKER
+    the batch is flattened into three tensors (every float of every item back to back, the integer metadata, the scales):
+    a list of 32 nine-tuples is 288 tensors, each its own shared-memory segment and file descriptor on the way to the main
+    process and again through the pinning thread -- measured 600 pairs/s from files with workers against 1 300 without;
+    three tensors per batch cost nothing.  ``unpack_batch`` turns them back into the same 9-tuples (views of the one
+    buffer, bit-identical values)."""
+    if torch.utils.data.get_worker_info() is None:
+        return list(items)
+    flats, meta, scales = [], [], []
+    for src, tgt, rot, trans, s, idx, cov, c, scene in items:
+        flats += [src.reshape(-1), tgt.reshape(-1), rot.reshape(-1), trans.reshape(-1), c.reshape(-1), cov.reshape(-1)]
+        meta.append([src.shape[0], tgt.shape[0], int(idx[0]), int(idx[1]), int(scene), cov.shape[0], cov.shape[1]])
+        scales.append(float(s))
+    return (_PACKED, torch.cat([f.float() for f in flats]), torch.tensor(meta, dtype=torch.int64), torch.tensor(scales, dtype=torch.float64))
+
+
+def unpack_batch(batch) -> List[tuple]:
+    """Inverse of the worker-side collation (a plain list of 9-tuples passes through)."""
+    if not (isinstance(batch, (tuple, list)) and len(batch) == 4 and isinstance(batch[0], str) and batch[0] == _PACKED):
+        return list(batch)
+    _, flat, meta, scales = batch
+    out, o = [], 0
+
+    def take(n, *shape):
+        nonlocal o
+        v = flat[o:o + n].view(*shape)
+        o += n
+        return v
+    for (n, m, i0, i1, scene, cr, cc), s in zip(meta.tolist(), scales.tolist()):
+        src, tgt = take(3 * n, n, 3), take(3 * m, m, 3)
+        rot, trans, c, cov = take(9, 3, 3), take(3, 3, 1), take(3, 3), take(cr * cc, cr, cc)
+        out.append((src, tgt, rot, trans, s, torch.LongTensor([i0, i1]), cov, c, scene))
+    return out

@@ -18,6 +18,7 @@ Deliberate differences from evaluate_3d_match.py, all documented in DESIGN.md:
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Callable, Iterable, List, Optional, Sequence
 
@@ -27,7 +28,7 @@ import torch
 from . import dist as sdist
 from . import lanes as _lanes
 from . import ops
-from .data import SCENE_NAMES, collate_pairs
+from .data import SCENE_NAMES, collate_pairs, unpack_batch
 from .geometry import processbar, register_batch
 from .packing import PackedBatch, StagingBuffers
 
@@ -149,28 +150,35 @@ def _register_lane(net, its, centers, pair_ids, corr, dis_thresh, icp, icp_dist,
 def register_items_async(net, its: Sequence[tuple], centers: Sequence[torch.Tensor], pair_ids: Sequence[int],
                          corr: str = "tgt", dis_thresh: float = 0.1, icp=None, icp_dist: float = ICP_MAX_CORR_DIST,
                          icp_iters: int = ICP_MAX_ITER, device: Optional[torch.device] = None,
-                         pred_hook: Optional[Callable] = None, lanes: Optional[int] = None) -> Callable[[], tuple]:
+                         pred_hook: Optional[Callable] = None, lanes: Optional[int] = None,
+                         stream: Optional[torch.cuda.Stream] = None) -> Callable[[], tuple]:
     """Enqueue A1-A10 (+ optional GPU ICP) for one batch and return ``finish()``, which waits for the device and gives
     the host arrays of register_items.  Everything between the call and ``finish()`` overlaps the GPU work, which is
-    how evaluate_loader hides the host side of batch i-1 and the packing of batch i+1 behind batch i."""
+    how evaluate_loader hides the host side of batch i-1 and the packing of batch i+1 behind batch i.
+    ``stream``: run the WHOLE batch -- one packed forward, search, solve, ICP, result copy -- on that stream and leave the
+    current stream alone (evaluate_loader alternates two such streams between consecutive batches, below)."""
     device = device or next(net.parameters()).device
+    if stream is not None:
+        lanes = 1
+        stream.wait_stream(torch.cuda.current_stream(device))  # (normally idle: orders the batch behind whatever the caller queued)
     if lanes is None:
         lanes = _lanes.DEFAULT_LANES if len(its) >= 8 else 1
     parts = _lanes.split_weighted([it[0].shape[0] + it[1].shape[0] for it in its], lanes)
-    outs = _lanes.run(device, parts, lambda rg: _register_lane(
-        net, [its[i] for i in rg], [centers[i] for i in rg], [pair_ids[i] for i in rg], corr, dis_thresh, icp, icp_dist,
-        icp_iters, device, pred_hook))
-    T = torch.cat([o[0] for o in outs])
-    T_gt = torch.cat([o[1] for o in outs])
-    T_gt_d = torch.cat([o[2] for o in outs])
-    re, te = torch.cat([o[3] for o in outs]), torch.cat([o[4] for o in outs])
-    loss = torch.cat([o[5] for o in outs]).reshape(-1)
-    # one small device buffer -> one asynchronous D2H copy into pinned memory
-    flat = torch.cat([T.reshape(-1), re, te, loss]).float()
-    host = torch.empty(flat.shape, dtype=torch.float32, pin_memory=True)
-    host.copy_(flat, non_blocking=True)
-    done = torch.cuda.Event()
-    done.record(torch.cuda.current_stream(device))
+    with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+        outs = _lanes.run(device, parts, lambda rg: _register_lane(
+            net, [its[i] for i in rg], [centers[i] for i in rg], [pair_ids[i] for i in rg], corr, dis_thresh, icp, icp_dist,
+            icp_iters, device, pred_hook))
+        T = torch.cat([o[0] for o in outs])
+        T_gt = torch.cat([o[1] for o in outs])
+        T_gt_d = torch.cat([o[2] for o in outs])
+        re, te = torch.cat([o[3] for o in outs]), torch.cat([o[4] for o in outs])
+        loss = torch.cat([o[5] for o in outs]).reshape(-1)
+        # one small device buffer -> one asynchronous D2H copy into pinned memory
+        flat = torch.cat([T.reshape(-1), re, te, loss]).float()
+        host = torch.empty(flat.shape, dtype=torch.float32, pin_memory=True)
+        host.copy_(flat, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(device))
     keep = [outs, flat]  # lane-stream allocations stay referenced until the copy has been consumed
 
     def finish():
@@ -204,12 +212,14 @@ def register_items(net, its: Sequence[tuple], centers: Sequence[torch.Tensor], p
 
 
 def evaluate_items_async(net, items: Sequence[tuple], pair_ids: Sequence[int], corr: str = "tgt", dis_thresh: float = 0.1,
-                         icp=None, device: Optional[torch.device] = None, pred_hook: Optional[Callable] = None):
+                         icp=None, device: Optional[torch.device] = None, pred_hook: Optional[Callable] = None,
+                         stream: Optional[torch.cuda.Stream] = None):
     """Enqueue one 3DMatch-family batch (items are the reference's 9-tuples); returns ``finish() -> rows [B, 8]``."""
     its = [_strip(it) for it in items]
     core = [(it[0], it[1], it[2], it[3], it[4], it[7]) for it in its]
     centers = [it[3] for it in its]  # src_center = trans^T, evaluate_3d_match.py:84
-    fin = register_items_async(net, core, centers, pair_ids, corr, dis_thresh, icp, device=device, pred_hook=pred_hook)
+    fin = register_items_async(net, core, centers, pair_ids, corr, dis_thresh, icp, device=device, pred_hook=pred_hook,
+                               stream=stream)
 
     def finish():
         T_h, T_gt, re_h, te_h, loss = fin()
@@ -232,7 +242,8 @@ def evaluate_items(net, items: Sequence[tuple], pair_ids: Sequence[int], corr: s
 
 def evaluate_loader(net, loader: Iterable, corr: str = "tgt", dis_thresh: float = 0.1,
                     re_static_method: str = "median", batch_pairs: int = 32, icp="gpu",
-                    verbose: bool = True, pred_hook: Optional[Callable] = None, num_workers: int = 0):
+                    verbose: bool = True, pred_hook: Optional[Callable] = None, num_workers: int = 0,
+                    worker_context: Optional[str] = None):
     """evaluate_3d_match.py:53-171.  ``loader`` is a dataset or DataLoader of the reference's 9-tuples.
     ``icp="gpu"`` (default) refines every pose like evaluate_3d_match.py:106-119 does; ``icp=None`` skips it.
     With torch.distributed initialised the pairs are sharded round-robin over ranks and the per-pair rows
@@ -243,11 +254,14 @@ def evaluate_loader(net, loader: Iterable, corr: str = "tgt", dis_thresh: float 
     mine = sdist.shard_indices(n, rank, world)
     rows: List[np.ndarray] = []
     done = 0
-    # var-len batches are lists of items; worker processes overlap file I/O + normalisation (or synthetic
-    # generation) with the GPU work of the previous batch, pinned so the H2D copies are asynchronous
+    # var-len batches are lists of items; worker processes overlap file I/O + normalisation (or synthetic generation) with
+    # the GPU work of the previous batch.  NOT pin_memory=True: the batch is repacked on the host into this module's own
+    # pinned staging buffers anyway (PackedBatch.from_host), and reading a batch back out of the loader's pinned copy --
+    # page-locked memory that the CPU reads uncached on this platform -- cost more than the file I/O it overlapped
+    # (690 pairs/s with workers against 1 330 without, tools/eval_e2e.py, until round 3).
     batches = torch.utils.data.DataLoader(torch.utils.data.Subset(dataset, mine), batch_size=batch_pairs, shuffle=False,
-                                          collate_fn=collate_pairs, num_workers=num_workers,
-                                          pin_memory=num_workers > 0 and torch.cuda.is_available())
+                                          collate_fn=collate_pairs, num_workers=num_workers, pin_memory=False,
+                                          multiprocessing_context=worker_context if num_workers > 0 else None)
     def collect(finish, n_done):
         r = finish()
         rows.append(r)
@@ -256,10 +270,19 @@ def evaluate_loader(net, loader: Iterable, corr: str = "tgt", dis_thresh: float 
                 processbar(n_done, len(mine)), r[-1, sdist.COL_RE], r[-1, sdist.COL_TE], r[-1, sdist.COL_RMSE],
                 float(np.concatenate(rows)[:, sdist.COL_SUCCESS].mean())), end="")
 
-    pending = None  # batch i is enqueued before the host side of batch i-1 runs: the GPU never waits for the host
+    # Batch i is enqueued before the host side of batch i-1 runs: the GPU never waits for the host.  Consecutive batches go to
+    # two alternating HIP streams, each batch whole (one packed forward of all its pairs): two batches are then in flight
+    # out of phase, and the launch-bound end of one -- the ICP loop is ~60 tiny dependent launches -- runs beside the
+    # other's forward instead of beside nothing (two lanes INSIDE a batch finish together and both sit in their ICP loops
+    # at the same time: 1 373 vs 1 570 pairs/s with / without ICP; results are the same either way, pairs never interact).
+    dev = next(net.parameters()).device if hasattr(net, "parameters") else None
+    streams = _lanes.lane_streams(dev, 2) if dev is not None and dev.type == "cuda" else [None, None]
+    pending, k = None, 0
     for items in batches:
+        items = unpack_batch(items)  # (worker processes send a batch as three flat tensors, scream_amd/data.py)
         ids = mine[done:done + len(items)]
-        fin = evaluate_items_async(net, items, ids, corr, dis_thresh, icp, pred_hook=pred_hook)
+        fin = evaluate_items_async(net, items, ids, corr, dis_thresh, icp, pred_hook=pred_hook, stream=streams[k % 2])
+        k += 1
         if pending is not None:
             collect(*pending)
         done += len(ids)

@@ -125,21 +125,26 @@ def test_open_gf_files_equal_in_memory_samples(tmp_path):
 
 
 def test_prefetching_loader_yields_the_same_items_in_order(golden, tmp_path):
-    """evaluate_loader's DataLoader (worker processes, var-len collate) over the file dataset: same items, same order."""
-    from scream_amd.data import collate_pairs
+    """evaluate_loader's DataLoader (worker processes, var-len collate) over the file dataset: same items, same order.
+    A worker ships a batch as three flat tensors (collate_pairs in a worker process); unpack_batch restores the 9-tuples
+    bit for bit -- dtypes, shapes and values -- and passes an in-process batch (a plain list) through."""
+    from scream_amd.data import collate_pairs, unpack_batch
     g = golden("dataset_items")
     write_split(g, "3DMatch_test", str(tmp_path / "3DMatch_test"))
     ds = PairFileDataset(str(tmp_path / "3DMatch_test"))
     dl = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, collate_fn=collate_pairs, num_workers=2)
-    flat = [it for batch in dl for it in batch]
+    batches = list(dl)
+    assert all(isinstance(b, (tuple, list)) and isinstance(b[0], str) and len(b) == 4 for b in batches)  # the packed form
+    flat = [it for batch in batches for it in unpack_batch(batch)]
     assert len(flat) == 3
+    assert unpack_batch([ds[0], ds[1]])[1][0] is not None and len(unpack_batch(collate_pairs([ds[0]]))) == 1  # main-process path: a list
     for i, it in enumerate(flat):
         ref = ds[i]
         for a, b in zip(it, ref):
             if torch.is_tensor(a):
-                assert torch.equal(a, b)
+                assert torch.equal(a, b) and a.dtype == b.dtype and a.shape == b.shape
             else:
-                assert a == b
+                assert a == b and type(a) == type(b)
 
 
 @pytest.mark.gpu

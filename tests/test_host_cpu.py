@@ -201,7 +201,7 @@ class DS:
     def __len__(self): return n
     def __getitem__(self, i): return i
 
-def fake_items(net, items, ids, corr, dis_thresh, icp, device=None, pred_hook=None):
+def fake_items(net, items, ids, corr, dis_thresh, icp, device=None, pred_hook=None, stream=None):
     rows = np.zeros((len(ids), sdist.ROW_WIDTH))
     for k, i in enumerate(ids):
         rows[k] = [i, i %% 8, 1.0, float(i %% 3 != 0), 1.0 + i, 0.01 * i, 0.1, 0.5 * i]
@@ -429,6 +429,19 @@ def test_the_static_checker_detects_what_it_is_there_for():
         s_waitcnt vmcnt(0)
     """)
     assert len(chk.check_kernel("k", acc)) == 1   # loads into accumulation registers are tracked as well
+    # (1b) the round-2 aperture violation (gpurun_out/r2i, DESIGN.md section 4): an ablation build WITHOUT the weight DMA kept
+    # the ring's counted wait -- vmcnt(12) leaves "the twelve pieces of the next stage" in flight, but no piece had been issued,
+    # so the row operand requested just before was still pending when the MFMA consumed it (and later landed in a register the
+    # allocator had recycled as a 64-bit address).  With the pieces in the queue the same wait is sound.
+    r2i = lines("""
+        global_load_dwordx4 v[4:7], v0, s[2:3]
+        s_waitcnt vmcnt(12)
+        v_mfma_f32_32x32x16_bf16 a[0:15], v[4:7], v[8:11], a[0:15]
+    """)
+    assert [b[2] for b in chk.check_kernel("k", r2i)] == [[4, 5, 6, 7]]
+    sound = lines("global_load_dwordx4 v[4:7], v0, s[2:3]\n" + "global_load_lds_dwordx4 v1, s[4:5]\n" * 12 +
+                  "s_waitcnt vmcnt(12)\nv_mfma_f32_32x32x16_bf16 a[0:15], v[4:7], v[8:11], a[0:15]")
+    assert not chk.check_kernel("k", sound)
     # (2) a scalar base restored by a VALU instruction right in front of the memory instruction that uses it
     hz = lines("""
         v_readlane_b32 s1, v255, 19
@@ -450,6 +463,32 @@ def test_the_static_checker_detects_what_it_is_there_for():
     assert len(chk.check_store_data_hazard("k", sd)) == 1
     assert not chk.check_store_data_hazard("k", lines("global_store_dwordx4 v240, v[0:3], s[0:1]\ns_nop 1\nv_mov_b32_e32 v1, 0"))
     assert not chk.check_store_data_hazard("k", lines("global_store_dword v240, v1, s[0:1]\nv_mov_b32_e32 v1, 0"))  # 32-bit data: none
+
+
+def test_tuning_builds_are_verified_before_they_can_be_launched(tmp_path):
+    """tools/tail_ablate.py / tail_stamps.py / x3_ablate.py / x3_stamps.py compile -D variants of the two hand-scheduled kernels;
+    every variant goes through asm_inflight_check.verify_source first (round 2 launched an unverified one and faulted the GPU).
+    The "no weight DMA" variant of the fp16 layer tail -- the variant that faulted, now with draining waits -- passes; a
+    variant in which hipcc moves a pending register raises instead of producing a library."""
+    import shutil
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import asm_inflight_check as chk
+    src = os.path.join(REPO, "scream_amd", "csrc", "tail_split.hip")
+    assert chk.verify_source(src, ["-ffp-contract=off", "-DT_ABLATE=1"], str(tmp_path / "t1.s"), "11tail_kernelINS_7SplitH2") == 1
+    bad = tmp_path / "bad.hip"  # a register load consumed behind a wait that does not cover it
+    bad.write_text("""#include <hip/hip_runtime.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void k(const float* p, float* o) {
+    f32x4 d;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p + threadIdx.x * 4));
+    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    o[threadIdx.x] = d[0] + d[1];
+}
+""")
+    with pytest.raises(RuntimeError, match="still in flight"):
+        chk.verify_source(str(bad), [], str(tmp_path / "bad.s"))
 
 
 def test_f32_kernel_k_loop_has_no_register_spills(tmp_path):

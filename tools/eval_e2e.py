@@ -22,12 +22,28 @@ def gen_raw(i):
     return synthetic.make_3dmatch_pair(i, "3dmatch")
 
 
+class CycledFiles:  # (module level: picklable for spawned loader workers) every file of the split directory n / D times
+    def __init__(self, root, n, d):
+        self.root, self.n, self.d, self.files = root, n, d, None
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if self.files is None:
+            from scream_amd.data import PairFileDataset
+            self.files = PairFileDataset(self.root)
+        return self.files[i % self.d]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("n", nargs="?", type=int, default=2048)
     ap.add_argument("--distinct", type=int, default=256)
     ap.add_argument("--gen-procs", type=int, default=14, help="1 = generate in-process (e.g. under rocprofv3)")
     ap.add_argument("--workers", default="0,2,4,8,12")
+    ap.add_argument("--torch-threads", type=int, default=0, help="torch.set_num_threads() of the main process (0 = leave)")
+    ap.add_argument("--worker-context", default=None, help="multiprocessing context of the loader workers (fork | spawn | forkserver)")
     args = ap.parse_args()
     D = min(args.distinct, args.n)
     if args.gen_procs > 1:  # before anything touches the GPU
@@ -43,6 +59,9 @@ def main():
     from scream_amd.model import PointTransformer
     from scream_amd.synthetic import make_state_dict
     scene_dirs = {v: k for k, v in SCENE_DIR_TO_IDX.items()}
+    if args.torch_threads:
+        torch.set_num_threads(args.torch_threads)
+    print("host: %d cores in the affinity mask, torch intra-op threads %d, OMP_NUM_THREADS=%s" % (len(os.sched_getaffinity(0)), torch.get_num_threads(), os.environ.get("OMP_NUM_THREADS")), flush=True)
 
     def item(r):
         src, tgt, T, idx, cov, scene = r
@@ -60,11 +79,21 @@ def main():
     evaluate_loader(net, torch.utils.data.Subset(Mem(), range(64)), batch_pairs=32, verbose=False)  # warm-up
 
     def leg(tag, ds, **kw):
+        # `steady`: from the moment the first batch reaches the GPU path (worker processes forked, first files read) to the end --
+        # starting a DataLoader's worker processes costs 1-2 s once per pass, whatever the dataset's length
+        first = []
+
+        def hook(batch, src_pred, pair_ids):
+            if not first:
+                first.append((time.perf_counter(), len(pair_ids)))
+            return src_pred
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        out = evaluate_loader(net, ds, batch_pairs=32, verbose=False, **kw)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print("%-46s %5d pairs in %6.2f s -> %7.1f pairs/s   (loss, rre, rte, rr) = %s" % (tag, len(ds), dt, len(ds) / dt, tuple(round(float(v), 4) for v in out)), flush=True)
-        return len(ds) / dt, out
+        out = evaluate_loader(net, ds, batch_pairs=32, verbose=False, pred_hook=hook, **kw)
+        torch.cuda.synchronize(); t1 = time.perf_counter(); dt = t1 - t0
+        steady = (len(ds) - 32) / (t1 - first[0][0])
+        print("%-46s %5d pairs in %6.2f s -> %7.1f pairs/s  (steady %7.1f, start-up %.2f s)   (loss, rre, rte, rr) = %s"
+              % (tag, len(ds), dt, len(ds) / dt, steady, first[0][0] - t0, tuple(round(float(v), 4) for v in out)), flush=True)
+        return steady, out
     leg("1. in-memory, icp=None", Mem(), icp=None)
     mem_rate, mem_out = leg("2. in-memory, icp='gpu' (reference default)", Mem(), icp="gpu")
 
@@ -78,18 +107,14 @@ def main():
             np.save(os.path.join(root, "info", "covariance%d.npy" % i), np.asarray(cov))
         with open(os.path.join(root, "info", "scene_names.txt"), "w") as f:
             f.write("\n".join(scene_dirs[r[5]] for r in raw) + "\n")
-        files = PairFileDataset(root)
-
-        class Cycled(torch.utils.data.Dataset):  # every file n / D times
-            def __len__(self): return args.n
-            def __getitem__(self, i): return files[i % D]
         best = None
         for k in [int(v) for v in args.workers.split(",")]:
-            rate, out = leg("3. from files, icp='gpu', num_workers=%d" % k, Cycled(), icp="gpu", num_workers=k)
+            rate, out = leg("3. from files, icp='gpu', num_workers=%d%s" % (k, " (%s)" % args.worker_context if args.worker_context and k else ""),
+                            CycledFiles(root, args.n, D), icp="gpu", num_workers=k, worker_context=args.worker_context)
             assert all(abs(float(a) - float(b)) < 1e-9 for a, b in zip(out, mem_out)), "from-files results differ from in-memory"
             if best is None and rate >= 0.95 * mem_rate:
                 best = k
-        print("smallest num_workers that sustains >= 95 %% of the in-memory rate (%.1f pairs/s): %s" % (mem_rate, best), flush=True)
+        print("smallest num_workers whose steady rate is >= 95 %% of the in-memory steady rate (%.1f pairs/s): %s" % (mem_rate, best), flush=True)
 
 
 if __name__ == "__main__":

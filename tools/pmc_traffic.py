@@ -41,6 +41,7 @@ def short(name):
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
     lanes = int(sys.argv[sys.argv.index("--lanes") + 1]) if "--lanes" in sys.argv else 1
+    backend = sys.argv[sys.argv.index("--backend") + 1] if "--backend" in sys.argv else os.environ.get("SCREAM_GEMM", "h2")
     fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
     steps_f = sum(v[0] for k, v in fe.items() if "pe_embed_ln_kernel" in k) / lanes
     steps_w = sum(v[0] for k, v in wr.items() if "pe_embed_ln_kernel" in k) / lanes
@@ -61,7 +62,7 @@ def main():
         e["write_bytes_per_launch"] = e["write_bytes_per_step"] * steps_w / max(e["dispatches_write_pass"], 1)
     rec = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py, summarised by tools/pmc_traffic.py",
            "corrections": "KB -> bytes; FETCH_SIZE x 2 (gfx950: 16 B/lane coalesced reads are reported at half); WRITE_SIZE exact",
-           "lanes": lanes, "steps_in_fetch_pass": steps_f, "steps_in_write_pass": steps_w,
+           "lanes": lanes, "gemm_backend": backend, "steps_in_fetch_pass": steps_f, "steps_in_write_pass": steps_w,
            "fetch_bytes_per_step": sum(e["fetch_bytes_per_step"] for e in kernels.values()),
            "write_bytes_per_step": sum(e["write_bytes_per_step"] for e in kernels.values()),
            "kernels": {k: {kk: (round(vv, 1) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in sorted(kernels.items(), key=lambda kv: -(kv[1]["fetch_bytes_per_step"] + kv[1]["write_bytes_per_step"]))}}
