@@ -49,11 +49,11 @@ sys.path.insert(0, REPO)
 PAIRS_PER_GPU = 32
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_16BIT_DENSE_TFLOPS = 2500.0  # same table, bf16 and fp16; the split kernels spend 3 (fp16 x 2) or 6 (bf16 x 3) MFMAs per fp32 product
-MFMAS_PER_PRODUCT = {"h2": 3, "x3": 6, "f32": 1}
+MFMAS_PER_PRODUCT = {"h2": 3, "x3": 6, "f32": 1, "h1": 1}  # "h1": the labelled fp16 autocast mirror (SCREAM_GEMM=h1), never the headline
 # context only, never `peak`: what a pure stream of v_mfma_f32_32x32x16_{bf16,f16} on random register operands sustains at
 # the 1400 W socket cap (tools/ubench/mfma_energy.py: profiles/r02_ubench_mfma_energy.txt 1.84 PFLOP/s bf16 at 1.80 GHz;
 # profiles/r03_ubench_mfma_energy.txt 1.63 PFLOP/s fp16 at 1.63 GHz on a box whose bf16 row read 1.76)
-MEASURED_MFMA_AT_POWER_CAP_TFLOPS = {"x3": 1840.0, "h2": 1627.0}
+MEASURED_MFMA_AT_POWER_CAP_TFLOPS = {"x3": 1840.0, "h2": 1627.0, "h1": 1627.0}
 GEMM_NAMES = {0: "gemm<EPI_NONE>", 1: "gemm<EPI_ELU1> (cross-layer q projection)",
               5: "gemm<EPI_QKV> (q/k/v projection + fused K^T V reduce)",
               7: "tail_kernel (attention apply, merge + LayerNorm1, FFN + LayerNorm2 in one launch; N = 256 + 2 x 1024 columns)",
@@ -472,13 +472,13 @@ def main():
                      for k_, v in sorted(by_shape.items())]
 
     gb = net.gemm_backend
-    split_backend = gb in ("h2", "x3")
+    split_backend = gb in ("h2", "x3", "h1")
     n_prod = MFMAS_PER_PRODUCT[gb]
     fused = split_backend and net.fused_tail
     # ---- HBM traffic: algorithmic bytes computed here, counter bytes from the committed PMC record of this command
     algo_b = sum(activation_bytes_per_pair(n, m, fused)[0] for n, m in zip(src_len, tgt_len))
     design_b = sum(activation_bytes_per_pair(n, m, fused)[1] for n, m in zip(src_len, tgt_len))
-    weight_b = float(sum(p.numel() for p in net.parameters()) * {"h2": 4, "x3": 6, "f32": 4}[gb])  # every weight image is read at least once per step
+    weight_b = float(sum(p.numel() for p in net.parameters()) * {"h2": 4, "x3": 6, "f32": 4, "h1": 2}[gb])  # every weight image is read at least once per step
     trec, tpath = load_traffic_record()
     traffic = None
     if trec is not None:
@@ -502,6 +502,7 @@ def main():
                     "flops of SURVEY.md 8d over the time a GEMM-class launch was running; the attention-apply products and the "
                     "fused K^T V epilogue's own MFMAs are not counted)")
                    % (("SplitH2", "SplitH2", "2 fp16 planes with weight-derived power-of-two scales", 3, "f16", 3) if gb == "h2" else
+                      ("SplitH1", "SplitH1", "ONE fp16 plane -- the reference's autocast mode, NOT fp32-accurate", 1, "f16", 1) if gb == "h1" else
                       ("SplitBf3", "SplitBf3", "3 bf16 planes", 6, "bf16", 6))) if split_backend else \
                   ("gemm_f32_kernel (v_mfma_f32_32x32x2_f32; all epilogue instantiations; the fused K^T V epilogue's own "
                    "MFMAs are not counted as algorithmic flops)")
@@ -513,7 +514,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "sustained_value": None if sustained is None else sustained[0],
             "sustained": None if sustained is None else {"steps": sustained[1], "seconds": sustained[2]},
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16 (autocast mirror; not the fp32 path)" if gb == "h1" else "f32", "data": "synthetic",
             "config": {"workload": {"3dmatch": "BASELINE configs[1]: synthetic 3DMatch_test-like pairs, voxel 0.0625 m, ~5k points/cloud",
                                     "kitti": "BASELINE configs[3]: synthetic KITTI_test-like pairs, voxel 0.7 m, ~13-16k points/cloud",
                                     "uniform64k": "BASELINE configs[4]: 65 536 uniform points per cloud"}[args.workload]

@@ -110,6 +110,9 @@ int scream_kv_finalize(const float* kv_partial, const int32_t* cloud_row0, const
  * models/pointnet.py:53-57); W is then the L matrices [k heads 0-3 | v 0-3 | k 4-7 | v 4-7] stacked, and layer l's partials
  * are written at kv_partial + l * (M/128) * 8 * 1056 floats.  layout (SCREAM_LAYOUT_* bits): A fragment-major needs lda == K == 256; C fragment-major applies to the
  * activated tile of an ELU1 / QKV epilogue with n_act == ldc == 256 (the queries). */
+#define SCREAM_SPLIT_H1 1 /* ONE fp16 plane, one product: NOT fp32-accurate (2^-11 per operand) -- the mirror of the reference's
+                            * `with autocast()` around the KITTI forward (evaluate_kitti.py:37); exponents as for SCREAM_SPLIT_H2;
+                            * explicit opt-in only (evaluate_kitti.evaluate(autocast=True)) */
 #define SCREAM_SPLIT_H2 2
 #define SCREAM_SPLIT_BF3 3
 int scream_pack_w_split(const float* W, int32_t N, int32_t K, int32_t split, int32_t w_exp, void* W_packed,

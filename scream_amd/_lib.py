@@ -21,7 +21,7 @@ c_u8p = C.POINTER(C.c_uint8)
 c_u64p = C.POINTER(C.c_uint64)
 
 
-SPLIT_H2, SPLIT_BF3 = 2, 3
+SPLIT_H1, SPLIT_H2, SPLIT_BF3 = 1, 2, 3
 
 
 class TailExpsT(C.Structure):

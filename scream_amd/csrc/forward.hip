@@ -281,7 +281,8 @@ extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t*
     const scream_model_t& m = *model;
     const scream_batch_t& b = *batch;
     SCREAM_REQUIRE(m.layers_host && m.n_self >= 0 && m.n_cross >= 0 &&
-                       (m.gemm_split == 0 || m.gemm_split == SCREAM_SPLIT_H2 || m.gemm_split == SCREAM_SPLIT_BF3), SCREAM_EINVAL);
+                       (m.gemm_split == 0 || m.gemm_split == SCREAM_SPLIT_H1 || m.gemm_split == SCREAM_SPLIT_H2 || m.gemm_split == SCREAM_SPLIT_BF3),
+                   SCREAM_EINVAL);
     SCREAM_REQUIRE(b.n_pairs > 0 && b.rows_src > 0 && b.rows_total > b.rows_src && b.max_chunks > 0, SCREAM_EINVAL);
     SCREAM_REQUIRE(b.rows_src % SCREAM_ROW_TILE == 0 && b.rows_total % SCREAM_ROW_TILE == 0, SCREAM_EUNSUPPORTED);
     SCREAM_REQUIRE(b.xyz && b.center && b.tile_cloud && b.cloud_row0 && b.cloud_len, SCREAM_EINVAL);

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_split_kernel(const float* __
                 // first MFMA, then the prefetch reads (one per plane), then the other MFMAs
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, SP::NPROD - 1, 0);
+                if (SP::NPROD > 1) __builtin_amdgcn_sched_group_barrier(0x008, SP::NPROD - 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -394,7 +394,7 @@ struct SplitArgs {
 
 bool split_args_ok(const SplitArgs& sa) {
     if (sa.split == SCREAM_SPLIT_BF3) return true;
-    return sa.split == SCREAM_SPLIT_H2 && sa.a_exp >= -60 && sa.a_exp <= 60 && sa.w_exp >= -60 && sa.w_exp <= 60;
+    return (sa.split == SCREAM_SPLIT_H2 || sa.split == SCREAM_SPLIT_H1) && sa.a_exp >= -60 && sa.a_exp <= 60 && sa.w_exp >= -60 && sa.w_exp <= 60;
 }
 
 template <class SP, int EPI>
@@ -420,6 +420,7 @@ template <int EPI>
 int launch_split(const float* A, int64_t lda, const void* Wp, float* C, int64_t ldc, int64_t M, int N, int K, const EpiArgs& ep,
                  hipStream_t st, bool a_frag, const SplitArgs& sa) {
     if (sa.split == SCREAM_SPLIT_H2) return launch_sp<SplitH2, EPI>(A, lda, Wp, C, ldc, M, N, K, ep, st, a_frag, sa);
+    if (sa.split == SCREAM_SPLIT_H1) return launch_sp<SplitH1, EPI>(A, lda, Wp, C, ldc, M, N, K, ep, st, a_frag, sa);
     return launch_sp<SplitBf3, EPI>(A, lda, Wp, C, ldc, M, N, K, ep, st, a_frag, sa);
 }
 
@@ -434,6 +435,8 @@ extern "C" int scream_pack_w_split(const float* W, int32_t N, int32_t K, int32_t
     const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
     if (split == SCREAM_SPLIT_H2)
         pack_w_kernel<SplitH2><<<grid, block, 0, as_stream(stream)>>>(W, N, K, exp2i(w_exp), reinterpret_cast<f16x8*>(packed));
+    else if (split == SCREAM_SPLIT_H1)
+        pack_w_kernel<SplitH1><<<grid, block, 0, as_stream(stream)>>>(W, N, K, exp2i(w_exp), reinterpret_cast<f16x8*>(packed));
     else
         pack_w_kernel<SplitBf3><<<grid, block, 0, as_stream(stream)>>>(W, N, K, 1.f, reinterpret_cast<bf16x8*>(packed));
     SCREAM_LAUNCH_CHECK();

@@ -32,23 +32,43 @@ __device__ __forceinline__ void grid_search_point(const GridParam& g, const int3
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
     float best = __builtin_inff();
     int bi = 0x7fffffff;
-    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.nz - 1); ++z)
-        for (int y = max(cy - 1, 0); y <= min(cy + 1, g.ny - 1); ++y) {
-            const int c0 = (z * g.ny + y) * g.nx;
-            const int jb = st[c0 + x0], je = st[c0 + x1 + 1];
-            for (int j = jb; j < je; ++j) {
-                const icp_f32x4 b = *reinterpret_cast<const icp_f32x4*>(sp + (int64_t)j * 4);
-                float dot = __fmul_rn(ax, b[0]);
-                dot = __fmaf_rn(ay, b[1], dot);
-                dot = __fmaf_rn(az, b[2], dot);
-                const float d = __fadd_rn(__fmaf_rn(-2.0f, dot, sa), b[3]);
-                const int o = si[j];
-                if (d < best || (d == best && o < bi)) {
-                    best = d;
-                    bi = o;
-                }
-            }
+    // The nine x-runs: all eighteen cell-start loads go out together (a thread's time here is memory latency: one dependent
+    // round per run cost 32 us per search launch), then the candidates of each run, four at a time.
+    int jb[9], je[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+        const bool in = z >= 0 && z < g.nz && y >= 0 && y < g.ny;
+        const int c0 = in ? (z * g.ny + y) * g.nx : 0;
+        jb[r] = st[c0 + x0];
+        je[r] = in ? st[c0 + x1 + 1] : jb[r];  // (an outside run is empty)
+    }
+    auto take = [&](const icp_f32x4& b, int o) {  // same explicitly rounded sequence as nn_search_kernel; ties -> lowest index
+        float dot = __fmul_rn(ax, b[0]);
+        dot = __fmaf_rn(ay, b[1], dot);
+        dot = __fmaf_rn(az, b[2], dot);
+        const float d = __fadd_rn(__fmaf_rn(-2.0f, dot, sa), b[3]);
+        if (d < best || (d == best && o < bi)) {
+            best = d;
+            bi = o;
         }
+    };
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        int j = jb[r];
+        for (; j + 4 <= je[r]; j += 4) {
+            icp_f32x4 b[4];
+            int o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                b[u] = *reinterpret_cast<const icp_f32x4*>(sp + (int64_t)(j + u) * 4);
+                o[u] = si[j + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) take(b[u], o[u]);
+        }
+        for (; j < je[r]; ++j) take(*reinterpret_cast<const icp_f32x4*>(sp + (int64_t)j * 4), si[j]);
+    }
     const bool ok = best < thresh;
     idx_out = ok ? bi : -1;
     d_out = ok ? best : __builtin_inff();

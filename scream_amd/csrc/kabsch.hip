@@ -165,7 +165,7 @@ __device__ void solve_pose(const double H[3][3], const float cA[3], const float 
 template <int NV, int NT = 256>
 __device__ void block_sum(double (&v)[NV], double* red /* [NT / 64][NV] */) {
     constexpr int NW = NT / 64;
-    static_assert(NW == 4 || NW == 16, "");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; ++k) v[k] = wave_sum_f64(v[k]);
@@ -181,7 +181,7 @@ __device__ void block_sum(double (&v)[NV], double* red /* [NT / 64][NV] */) {
 #pragma unroll
         for (int g = 0; g < NW / 4; ++g)
             q4[g] = (red[(4 * g + 0) * NV + k] + red[(4 * g + 1) * NV + k]) + (red[(4 * g + 2) * NV + k] + red[(4 * g + 3) * NV + k]);
-        v[k] = NW == 4 ? q4[0] : (q4[0] + q4[1 % (NW / 4)]) + (q4[2 % (NW / 4)] + q4[3 % (NW / 4)]);
+        v[k] = NW == 4 ? q4[0] : NW == 8 ? q4[0] + q4[1 % (NW / 4)] : (q4[0] + q4[1 % (NW / 4)]) + (q4[2 % (NW / 4)] + q4[3 % (NW / 4)]);
     }
 }
 
@@ -375,31 +375,65 @@ struct IcpState {  // per pair
     int32_t done, iters;
 };
 
-constexpr int ICP_NT = 1024;  // threads of an ICP workgroup (one workgroup per pair)
+constexpr int ICP_NT = 512;   // threads of an ICP update workgroup (one workgroup per pair)
+constexpr int ICP_KC = 16;    // correspondences a thread keeps in registers between the passes (pairs up to 8 192 points)
 
 // One workgroup (ICP_NT threads) per pair: fitness / inlier RMSE of the current correspondences, convergence test, and (if
 // the pair goes on) the Kabsch update composed into T.  q = transformed source, idx/valid/dmin from the search.  Returns
-// (block-uniform) whether the pair has stopped.  1024 threads since round 3 (256 before: three latency-bound passes of
-// dependent gathers over ~5 k points took 43 us per iteration, more than the search it follows).
-// (Tried in round 3 and dropped: the whole loop of a pair inside one workgroup, profiles/r03_icp_one_workgroup_loop.txt.)
-// (no __restrict__ on q / idx / valid / dmin / T / state: the one-launch loop writes them between calls)
+// (block-uniform) whether the pair has stopped.  Round 3: ONE gathering pass -- a thread's correspondences (a = q_i, b = its
+// target, the distance) stay in registers for the centroid-relative covariance pass, where rounds 1-2 walked the dependent
+// chain valid -> idx -> target row three times with 256 threads (43 us per launch, more than the search before it).  Same
+// formulas as kabsch_block (centroids sum / (K + 1e-6) in fp32, covariance of the fp32 differences summed in fp64); the
+// summation order is fixed by ICP_NT, so the grid and the brute-force search paths, which share this kernel, stay bit-identical.
 __device__ bool icp_update_block(int p, const float* q, const float* __restrict__ ref,
                                  const int32_t* __restrict__ src_row0, const int32_t* __restrict__ src_len,
                                  const int32_t* __restrict__ ref_row0, const int32_t* idx,
                                  const uint8_t* valid, const float* dmin, int iter, int max_iter,
                                  float rel_fitness, float rel_rmse, float* T, IcpState* state,
                                  int32_t* act_len, float* fit_rmse_out, int32_t* iters_out) {
-    __shared__ double red2[ICP_NT / 64 * 2];
+    __shared__ double red[ICP_NT / 64 * 9];
+    __shared__ float dT_sh[16];
     const IcpState st = state[p];
     const int n = src_len[p];
-    const int64_t r0 = src_row0[p];
-    double acc[2] = {0.0, 0.0};
-    for (int i = threadIdx.x; i < n; i += ICP_NT)
-        if (valid[r0 + i]) {
-            acc[0] += 1.0;
-            acc[1] += (double)dmin[r0 + i];
+    const int64_t r0 = src_row0[p], rr0 = ref_row0[p];
+    float ca[ICP_KC][3], cb[ICP_KC][3];
+    bool ok[ICP_KC];
+    auto fetch = [&](int i, float (&a)[3], float (&b)[3], float& d) {
+        const int64_t row = r0 + i;
+        if (!valid[row]) return false;
+        const int64_t rrow = rr0 + idx[row];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a[k] = q[row * 3 + k];
+            b[k] = ref[rrow * 3 + k];
         }
-    block_sum<2, ICP_NT>(acc, red2);
+        d = dmin[row];
+        return true;
+    };
+    double acc[8];  // count, sum d, sum a, sum b
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+    auto add1 = [&](const float (&a)[3], const float (&b)[3], float d) {
+        acc[0] += 1.0;
+        acc[1] += (double)d;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            acc[2 + k] += (double)a[k];
+            acc[5 + k] += (double)b[k];
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < ICP_KC; ++c) {
+        const int i = threadIdx.x + c * ICP_NT;
+        float d = 0.f;
+        ok[c] = i < n && fetch(i, ca[c], cb[c], d);
+        if (ok[c]) add1(ca[c], cb[c], d);
+    }
+    for (int i = threadIdx.x + ICP_KC * ICP_NT; i < n; i += ICP_NT) {  // (clouds beyond 8 192 points: the rest is re-fetched below)
+        float a[3], b[3], d;
+        if (fetch(i, a, b, d)) add1(a, b, d);
+    }
+    block_sum<8, ICP_NT>(acc, red);
     const float fitness = n > 0 ? (float)(acc[0] / n) : 0.f;
     const float rmse = acc[0] > 0 ? (float)sqrt(acc[1] / acc[0]) : 0.f;
     const bool converged = iter > 0 && fabsf(st.fitness - fitness) < rel_fitness && fabsf(st.rmse - rmse) < rel_rmse;
@@ -416,11 +450,40 @@ __device__ bool icp_update_block(int p, const float* q, const float* __restrict_
         if (stop) act_len[p] = 0;            // a finished pair costs no further transform / search work
     }
     if (stop) return true;
-    float v = 0.f;
-    CorrFetch f{q, ref, idx, valid, r0, ref_row0[p], 1.0f, 0.f, 0.f, 0.f, n};
-    __shared__ float dT_sh[16];
-    kabsch_block<CorrFetch, ICP_NT>(f, dT_sh, nullptr);
+    const float denom = (float)acc[0] + 1e-6f;  // utils.py:155-158 with unit weights
+    const float cA[3] = {(float)acc[2] / denom, (float)acc[3] / denom, (float)acc[4] / denom};
+    const float cB[3] = {(float)acc[5] / denom, (float)acc[6] / denom, (float)acc[7] / denom};
+    double h[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) h[k] = 0.0;
+    auto add2 = [&](const float (&a)[3], const float (&b)[3]) {
+        const float am[3] = {a[0] - cA[0], a[1] - cA[1], a[2] - cA[2]};
+        const float bm[3] = {b[0] - cB[0], b[1] - cB[1], b[2] - cB[2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) h[r * 3 + c] += (double)am[r] * (double)bm[c];
+    };
+#pragma unroll
+    for (int c = 0; c < ICP_KC; ++c)
+        if (ok[c]) add2(ca[c], cb[c]);
+    for (int i = threadIdx.x + ICP_KC * ICP_NT; i < n; i += ICP_NT) {
+        float a[3], b[3], d;
+        if (fetch(i, a, b, d)) add2(a, b);
+    }
+    block_sum<9, ICP_NT>(h, red);
+    if (threadIdx.x < 64) {  // wave 0, every lane redundantly (wave-uniform data)
+        double H[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) H[r][c] = (double)(float)h[r * 3 + c];
+        float dT[16];
+        solve_pose(H, cA, cB, dT);
+        if (threadIdx.x < 16) dT_sh[threadIdx.x] = dT[threadIdx.x];
+    }
     __syncthreads();
+    float v = 0.f;
     if (threadIdx.x < 16) {  // T <- dT . T
         const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
 #pragma unroll

@@ -20,7 +20,7 @@ constexpr int TT = 256;               // threads
 constexpr int T_SLOTS = 3;
 constexpr int T_MAX_GRID = 256;
 
-// one ring stage: 16 fragments of 1 KiB per operand plane (SplitBf3: 48 KiB, SplitH2: 32 KiB); a wave issues a quarter of
+// one ring stage: 16 fragments of 1 KiB per operand plane (SplitBf3: 48 KiB, SplitH2: 32 KiB, SplitH1: 16 KiB); a wave issues a quarter of
 // its LDS-DMA pieces
 template <class SP> constexpr int stage_bytes() { return SP::NP * 16 * 1024; }
 template <class SP> constexpr int wave_pieces() { return SP::NP * 4; }
@@ -94,7 +94,7 @@ __device__ __forceinline__ void mfma_group(f32x16& acc, const typename SP::vec (
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, SP::NP, 0);
     if (NV == 0) {
-        __builtin_amdgcn_sched_group_barrier(0x008, SP::NPROD - 1, 0);
+        if (SP::NPROD > 1) __builtin_amdgcn_sched_group_barrier(0x008, SP::NPROD - 1, 0);
     } else {
 #pragma unroll
         for (int i = 0; i < SP::NPROD - 1; ++i) {
@@ -141,8 +141,9 @@ __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 #define VM_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 template <int N>
 __device__ __forceinline__ void vm_wait() {  // N = the weight pieces that may stay in flight ("no DMA" tuning build: none exist, drain)
-    static_assert(N == 0 || N == 8 || N == 12, "");
+    static_assert(N == 0 || N == 4 || N == 8 || N == 12, "");
     if (N == 0 || (T_ABLATE & 1)) VM_WAIT(0);
+    else if (N == 4) VM_WAIT(4);
     else if (N == 8) VM_WAIT(8);
     else VM_WAIT(12);
 }

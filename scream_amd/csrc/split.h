@@ -79,6 +79,24 @@ struct SplitH2 {
     }
 };
 
+// ONE fp16 plane, one product: NOT an fp32-accurate split -- the mirror of the reference's own reduced-precision mode, the
+// `with autocast()` around the KITTI forward (evaluate_kitti.py:37: fp16 matrix products with fp32 accumulation on CUDA, a
+// no-op on the CPU path that parity is defined on).  Same kernels, same weight-derived exponents as SplitH2 (which also keep
+// every fp16 operand in range); selected only by an explicit autocast=True / gemm_backend "h1", never a default, never the
+// headline.  Error per product 2^-11 relative instead of 2^-22.
+struct SplitH1 {
+    static constexpr int NP = 1;
+    static constexpr int NPROD = 1;
+    static constexpr bool SCALED = true;
+    typedef f16x8 vec;
+    static __device__ __forceinline__ void split1(float x, int i, vec (&p)[1]) { p[0][i] = (_Float16)x; }
+    static __device__ __forceinline__ f32x16 mfma(vec a, vec b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    template <bool MIRROR = false>
+    static __device__ __forceinline__ void products(f32x16& acc, const vec (&x)[1], const vec (&y)[1], const f32x16& c0) {
+        acc = mfma(x[0], y[0], c0);
+    }
+};
+
 // eight consecutive operand values (two f32x4) -> planes (SplitH2: the values already carry the operand's 2^e)
 template <class SP>
 __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, typename SP::vec (&p)[SP::NP]) {

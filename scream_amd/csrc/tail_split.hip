@@ -771,7 +771,7 @@ __global__ __launch_bounds__(1024) void kv_finalize_x3_kernel(const float* __res
     }
 }
 
-bool split_ok(int32_t split) { return split == SCREAM_SPLIT_BF3 || split == SCREAM_SPLIT_H2; }
+bool split_ok(int32_t split) { return split == SCREAM_SPLIT_BF3 || split == SCREAM_SPLIT_H2 || split == SCREAM_SPLIT_H1; }
 
 // the kernel's factors from the six exponents; false if one leaves the range the arithmetic was checked for
 bool tail_scales(const scream_tail_exps_t* ex, TailScales* sc) {
@@ -804,11 +804,15 @@ extern "C" int scream_pack_tail(const float* Wm, const float* W1, const float* W
     SCREAM_REQUIRE(Wm && W1 && W2 && image && split_ok(split), SCREAM_EINVAL);
     SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, SCREAM_EINVAL);
     const dim3 grid(TAIL_STAGES * 16 * 64 / 256), block(256);
-    if (split == SCREAM_SPLIT_H2) {
+    if (split != SCREAM_SPLIT_BF3) {
         TailScales sc;
         SCREAM_REQUIRE(tail_scales(exps, &sc), SCREAM_EINVAL);
-        pack_tail_kernel<SplitH2><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, exp2i(exps->e_wm), exp2i(exps->e_w1), exp2i(exps->e_w2),
-                                                                         reinterpret_cast<f16x8*>(image));
+        if (split == SCREAM_SPLIT_H2)
+            pack_tail_kernel<SplitH2><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, exp2i(exps->e_wm), exp2i(exps->e_w1), exp2i(exps->e_w2),
+                                                                             reinterpret_cast<f16x8*>(image));
+        else
+            pack_tail_kernel<SplitH1><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, exp2i(exps->e_wm), exp2i(exps->e_w1), exp2i(exps->e_w2),
+                                                                             reinterpret_cast<f16x8*>(image));
     } else {
         pack_tail_kernel<SplitBf3><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, 1.f, 1.f, 1.f, reinterpret_cast<bf16x8*>(image));
     }
@@ -842,13 +846,17 @@ extern "C" int scream_layer_tail_f32(const float* Q, const void* kv_image, const
                      reinterpret_cast<uintptr_t>(g2) | reinterpret_cast<uintptr_t>(b2) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, SCREAM_EINVAL);
     SCREAM_REQUIRE(x != y, SCREAM_EINVAL);  // the residual of a row is read twice, long after its neighbours were written
     TailScales sc{1.f, 1.f, 1e-5f, 1.f, 1.f, 1.f, 1e-5f};
-    if (split == SCREAM_SPLIT_H2) SCREAM_REQUIRE(tail_scales(exps, &sc), SCREAM_EINVAL);
+    if (split != SCREAM_SPLIT_BF3) SCREAM_REQUIRE(tail_scales(exps, &sc), SCREAM_EINVAL);
     const int64_t tiles = M / SCREAM_ROW_TILE;
     if (tiles == 0) return 0;
     SCREAM_REQUIRE(tiles < (1ll << 31), SCREAM_EUNSUPPORTED);
     const unsigned grid = tiles < T_MAX_GRID ? (unsigned)tiles : (unsigned)T_MAX_GRID;
     if (split == SCREAM_SPLIT_H2)
         tail_kernel<SplitH2><<<dim3(grid), dim3(TT), 0, as_stream(stream)>>>(Q, reinterpret_cast<const char*>(kv_image), tile_cloud,
+                                                                             kv_cloud_offset, cloud_len, x, reinterpret_cast<const char*>(tail_image),
+                                                                             g1, b1, g2, b2, y, (int)tiles, sc);
+    else if (split == SCREAM_SPLIT_H1)
+        tail_kernel<SplitH1><<<dim3(grid), dim3(TT), 0, as_stream(stream)>>>(Q, reinterpret_cast<const char*>(kv_image), tile_cloud,
                                                                              kv_cloud_offset, cloud_len, x, reinterpret_cast<const char*>(tail_image),
                                                                              g1, b1, g2, b2, y, (int)tiles, sc);
     else

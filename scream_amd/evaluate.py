@@ -259,9 +259,16 @@ def evaluate_loader(net, loader: Iterable, corr: str = "tgt", dis_thresh: float 
     # pinned staging buffers anyway (PackedBatch.from_host), and reading a batch back out of the loader's pinned copy --
     # page-locked memory that the CPU reads uncached on this platform -- cost more than the file I/O it overlapped
     # (690 pairs/s with workers against 1 330 without, tools/eval_e2e.py, until round 3).
+    # Worker processes come from a FORK SERVER by default (worker_context=None): workers forked from this process -- one
+    # that has the GPU runtime initialised and gigabytes mapped -- delivered 650 pairs/s whatever their number, workers from a
+    # clean fork server 1 300 (tools/eval_e2e.py); the dataset must then be picklable, as the reference's module-level dataset
+    # classes are.  "fork" restores the torch default.
+    ctx = None
+    if num_workers > 0:
+        ctx = worker_context or ("forkserver" if torch.cuda.is_available() and torch.cuda.is_initialized() else None)
     batches = torch.utils.data.DataLoader(torch.utils.data.Subset(dataset, mine), batch_size=batch_pairs, shuffle=False,
                                           collate_fn=collate_pairs, num_workers=num_workers, pin_memory=False,
-                                          multiprocessing_context=worker_context if num_workers > 0 else None)
+                                          multiprocessing_context=ctx)
     def collect(finish, n_done):
         r = finish()
         rows.append(r)

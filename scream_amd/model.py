@@ -93,6 +93,8 @@ class PointTransformer(nn.Module):
     # power-of-two scales derived from the weights (scream_amd/scales.py), three products -- fp32-level accuracy at half the
     # matrix instructions of "x3" (bf16 matrix cores, three planes, six products; scale invariant, rounds 1-2);
     # "f32" = fp32-input MFMA.  All three are held to the same parity tolerances; SCREAM_GEMM overrides.
+    # "h1": ONE fp16 plane, one product -- NOT fp32-accurate: the mirror of the reference's `with autocast()` around the KITTI
+    # forward (evaluate_kitti.py:37); set only by evaluate_kitti.evaluate(autocast=True) or by hand, never a default.
     gemm_backend = os.environ.get("SCREAM_GEMM", "h2")
 
     # split backends only: attention apply, merge + LayerNorm1 and the FFN + LayerNorm2 as one launch per block
@@ -147,9 +149,10 @@ class PointTransformer(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
-        if self.gemm_backend not in ("h2", "x3", "f32"):
-            raise ValueError("gemm_backend must be 'h2', 'x3' or 'f32', got %r" % (self.gemm_backend,))
-        split = {"h2": _lib.SPLIT_H2, "x3": _lib.SPLIT_BF3, "f32": 0}[self.gemm_backend]
+        if self.gemm_backend not in ("h2", "x3", "f32", "h1"):
+            raise ValueError("gemm_backend must be 'h2', 'x3', 'f32' or 'h1', got %r" % (self.gemm_backend,))
+        split = {"h2": _lib.SPLIT_H2, "x3": _lib.SPLIT_BF3, "f32": 0, "h1": _lib.SPLIT_H1}[self.gemm_backend]
+        fp16_split = split in (_lib.SPLIT_H2, _lib.SPLIT_H1)  # the splits that carry power-of-two operand exponents
 
         def dev_mat(t):  # a weight MATRIX: fp32 [N,K], or its operand planes for the split GEMM; returns (pointer, exponent)
             if not split:
@@ -171,7 +174,7 @@ class PointTransformer(nn.Module):
             L.wqkv, L.e_wqkv = dev_mat(torch.cat([m.q_proj.weight, wkv], dim=0))
             L.wq, L.e_wq = dev_mat(m.q_proj.weight)
             L.wkv, L.e_wkv = dev_mat(wkv)
-            ex = scales.layer_exps(m, in_q, in_kv) if split == _lib.SPLIT_H2 else {}
+            ex = scales.layer_exps(m, in_q, in_kv) if fp16_split else {}
             L.e_xq, L.e_xkv = ex.get("e_xq", 0), ex.get("e_xkv", 0)
             L.tail_exps = ops.tail_exps(**ex)
             L.tail = None
@@ -207,7 +210,7 @@ class PointTransformer(nn.Module):
             stack = torch.cat([torch.cat([c.layer.k_proj.weight[:128], c.layer.v_proj.weight[:128], c.layer.k_proj.weight[128:],
                                           c.layer.v_proj.weight[128:]], dim=0) for c in cross], dim=0)
             mt.wkv_cross, mt.e_wkv_cross = dev_mat(stack)
-        if split == _lib.SPLIT_H2:  # coor_mlp (models/pointnet.py:27-33): LayerNorm2 output -> Conv1d + bias, relu -> Conv1d
+        if fp16_split:  # coor_mlp (models/pointnet.py:27-33): LayerNorm2 output -> Conv1d + bias, relu -> Conv1d
             mt.e_c0x = scales.exp_for(scales.ln_bound(*coor_in))
             mt.e_c2x = scales.exp_for(scales.lin_bound(c0w, *coor_in, bias=self.coor_mlp[0].bias))
         self._fused = self._fused_cfg(split)

@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib, scales
-from ._lib import SPLIT_BF3, SPLIT_H2, check
+from ._lib import SPLIT_BF3, SPLIT_H1, SPLIT_H2, check
 
 EPI_NONE, EPI_ELU1, EPI_RELU, EPI_BIAS_RELU, EPI_RES_LN, EPI_QKV = 0, 1, 2, 3, 4, 5
 ROW_TILE = 128
@@ -91,10 +91,10 @@ def pack_w(W: torch.Tensor, split: Optional[int] = None, w_exp: Optional[int] = 
     split = default_split() if split is None else split
     W = W.detach().to(torch.float32).contiguous()
     N, K = W.shape
-    if split == SPLIT_H2 and w_exp is None:
+    if split in (SPLIT_H2, SPLIT_H1) and w_exp is None:
         w_exp = scales.w_exp(W)
     w_exp = int(w_exp or 0)
-    dt = torch.float16 if split == SPLIT_H2 else torch.bfloat16
+    dt = torch.float16 if split in (SPLIT_H2, SPLIT_H1) else torch.bfloat16
     out = torch.empty(split, K // 32, N, 32, device=W.device, dtype=dt)
     check(_lib.load().scream_pack_w_split(_p(W), N, K, split, w_exp, _p(out, dt), _stream()), "scream_pack_w_split")
     return PackedW(out, split, w_exp, N, K)
@@ -115,7 +115,7 @@ def act_layout(X: torch.Tensor, to_fragment: bool) -> torch.Tensor:
 def _a_exp(A: torch.Tensor, Wp, a_exp: Optional[int]) -> int:
     """SPLIT_H2 needs |A| 2^a_exp <= 2^15.  Callers that know a bound pass it; the convenience default measures max|A|
     (a device synchronisation: tests and tools only -- the forward gets its exponents from the weights, scream_amd/scales.py)."""
-    if Wp.split != SPLIT_H2:
+    if Wp.split == SPLIT_BF3:
         return 0
     return scales.exp_for(A.abs().max().item()) if a_exp is None else int(a_exp)
 
@@ -152,8 +152,8 @@ def pack_tail(Wm: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, split: Optio
     split = default_split() if split is None else split
     Wm, W1, W2 = (w.detach().to(torch.float32).contiguous() for w in (Wm, W1, W2))
     assert Wm.shape == (D_MODEL, D_MODEL) and W1.shape == (4 * D_MODEL, D_MODEL) and W2.shape == (D_MODEL, 4 * D_MODEL)
-    if split == SPLIT_H2 and exps is None:
-        raise ValueError("pack_tail(split=SPLIT_H2) needs the operand exponents (scream_amd/scales.py)")
+    if split != SPLIT_BF3 and exps is None:
+        raise ValueError("pack_tail on an fp16 split needs the operand exponents (scream_amd/scales.py)")
     exps = exps if exps is not None else tail_exps()
     lib = _lib.load()
     out = torch.empty(lib.scream_tail_image_bytes(split), device=Wm.device, dtype=torch.uint8)

@@ -46,7 +46,7 @@ def test_host_side_argument_checks_need_no_gpu():
     # six cross layers' target-side K^T V partials (one 128-row target tile x 8 heads x 1056 floats) and images side by side
     assert lib.scream_forward_workspace_bytes(128, 256, 1, 1, 1, 6) - fused == 6 * (8 * 1056 * 4 + lib.scream_kv_image_bytes())
     # the split entry points validate `split` and the fp16 exponents on the host
-    assert lib.scream_tail_image_bytes(2) == 72 * 32 * 1024 and lib.scream_tail_image_bytes(3) == 72 * 48 * 1024
+    assert [lib.scream_tail_image_bytes(k) for k in (1, 2, 3)] == [72 * 16 * 1024, 72 * 32 * 1024, 72 * 48 * 1024]
     assert lib.scream_tail_image_bytes(4) == -1
     # NULL pointers / bad shapes are rejected before any launch
     assert lib.scream_gemm_f32(None, 256, None, None, 256, 128, 256, 256, 0, 0, None, None, 0, None, None, None) == -1
@@ -333,7 +333,7 @@ def test_split_kernel_k_loop_has_no_register_spills(tmp_path):
                    check=True, capture_output=True, timeout=600)
     lines = out.read_text().splitlines()
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN.*gemm_split_kernelINS_\d+Split\w+ELi\d+ELb[01]E.*:", l)]
-    assert len(starts) == 24  # two operand splits x six epilogues x two layouts of the A operand
+    assert len(starts) == 36  # three operand splits x six epilogues x two layouts of the A operand
     checked = 0
     for a, b in zip(starts, starts[1:] + [len(lines)]):
         body = lines[a:b]
@@ -348,15 +348,15 @@ def test_split_kernel_k_loop_has_no_register_spills(tmp_path):
 
         j = next(k for k in range(i, len(body)) if backward(k))
         loop = body[i:j]
-        h2 = "SplitH2" in body[0]
-        assert sum(("v_mfma_f32_32x32x16_f16" if h2 else "v_mfma_f32_32x32x16_bf16") in l for l in loop) == (144 if h2 else 288)  # three k-tiles of 48 / 96 MFMAs
+        n_prod = 1 if "SplitH1" in body[0] else 3 if "SplitH2" in body[0] else 6
+        assert sum(("v_mfma_f32_32x32x16_bf16" if n_prod == 6 else "v_mfma_f32_32x32x16_f16") in l for l in loop) == 48 * n_prod  # three k-tiles of 16 groups
         assert not any("scratch_" in l for l in loop), "register spill inside the x3 k-loop"
         # the first operand registers of the NEXT tile are in flight during the epilogue as well: spill stores are only
         # tolerated in the kernel prologue, where they save loop invariants
         outer = next(k for k, l in enumerate(body) if "Loop Header: Depth=1" in l)
         assert not any("scratch_store" in l for l in body[outer:]), "spill store inside the persistent tile loop"
         checked += 1
-    assert checked == 24
+    assert checked == 36
 
 
 def test_no_instruction_touches_a_register_whose_asm_load_is_pending(tmp_path):
@@ -398,7 +398,7 @@ def test_no_instruction_touches_a_register_whose_asm_load_is_pending(tmp_path):
                 assert not any(re.match(r"\s*scratch_", l) for l in body), "scratch traffic in " + want
                 drains = sum(1 for l in body if re.match(r"\s*s_waitcnt vmcnt\(0\)", l))
                 assert drains <= 8, drains
-        assert n_kernels == {"gemm_split.hip": 24, "tail_split.hip": 2}[src]  # both operand splits of each
+        assert n_kernels == {"gemm_split.hip": 36, "tail_split.hip": 3}[src]  # every operand split of each
 
 
 def test_the_static_checker_detects_what_it_is_there_for():
