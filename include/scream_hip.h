@@ -108,7 +108,9 @@ int scream_kv_finalize(const float* kv_partial, const int32_t* cloud_row0, const
  * operand on its own.  scream_gemm_qkv_split_f32 also takes N = 512 L with n_q == 0: the key/value projections of L layers
  * applied to the SAME rows as one GEMM (the cross stage's target side: the target features are frozen after the stem,
  * models/pointnet.py:53-57); W is then the L matrices [k heads 0-3 | v 0-3 | k 4-7 | v 4-7] stacked, and layer l's partials
- * are written at kv_partial + l * (M/128) * 8 * 1056 floats.  layout (SCREAM_LAYOUT_* bits): A fragment-major needs lda == K == 256; C fragment-major applies to the
+ * are written at kv_partial + l * (M/128) * 8 * 1056 floats.  k_exp / v_exp (fp16 splits; ignored on SCREAM_SPLIT_BF3): the K^T V
+ * reduction in the epilogue runs on fp16 x 2 planes of K' = elu(k) + 1 and V as well -- CONTRACT |K'| 2^k_exp, |V| 2^v_exp <= 2^15
+ * (|k| and |v| are bounded like any projection of a LayerNorm output; K' <= 1 + max(k, 0)).  layout (SCREAM_LAYOUT_* bits): A fragment-major needs lda == K == 256; C fragment-major applies to the
  * activated tile of an ELU1 / QKV epilogue with n_act == ldc == 256 (the queries). */
 #define SCREAM_SPLIT_H1 1 /* ONE fp16 plane, one product: NOT fp32-accurate (2^-11 per operand) -- the mirror of the reference's
                             * `with autocast()` around the KITTI forward (evaluate_kitti.py:37); exponents as for SCREAM_SPLIT_H2;
@@ -125,7 +127,7 @@ int scream_gemm_qkv_split_f32(const float* A, int64_t lda, const void* W_packed,
                               int64_t M, int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
                               const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
                               float* kv_partial, int32_t layout, int32_t split, int32_t a_exp, int32_t w_exp,
-                              void* stream);
+                              int32_t k_exp, int32_t v_exp, void* stream);
 
 /* ---- A3 (apply) + A4 as ONE launch: everything of an MHAttention block that is local to a row,
  *     att = ((Q' . KV) * Z) * S;  m1 = LayerNorm1(att . Wm^T + x);  y = LayerNorm2(x + W2 . relu(W1 . m1))
@@ -220,6 +222,7 @@ typedef struct {
      * e_wkv, e_wm_g, e_w1_g, e_w2_g: of the packed matrices above (the *_g ones only when wm / w1 / w2 run as separate GEMMs,
      * with e_att / e_m1 / e_h of tail_exps as their input exponents); tail_exps: of the fused tail and its image. */
     int32_t e_xq, e_xkv, e_wqkv, e_wq, e_wkv, e_wm_g, e_w1_g, e_w2_g;
+    int32_t e_k, e_v; /* of K' = elu(k) + 1 and of V in the projection's K^T V epilogue */
     scream_tail_exps_t tail_exps;
 } scream_layer_t;
 
@@ -248,7 +251,7 @@ typedef struct {
      * one launch right after the stem (and finalises their K^T V images in one) instead of once per layer, and ignores the
      * cross layers' wkv / e_wkv. */
     const float* wkv_cross;
-    int32_t e_wkv_cross;
+    int32_t e_wkv_cross, e_k_cross, e_v_cross; /* e_k / e_v: the smallest over the cross layers */
 } scream_model_t;
 
 typedef struct {

@@ -30,7 +30,7 @@ class TailExpsT(C.Structure):
 
 class LayerT(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("wqkv", "wq", "wkv", "wm", "w1", "w2", "g1", "b1", "g2", "b2", "tail")] +
-                [(n, C.c_int32) for n in ("e_xq", "e_xkv", "e_wqkv", "e_wq", "e_wkv", "e_wm_g", "e_w1_g", "e_w2_g")] +
+                [(n, C.c_int32) for n in ("e_xq", "e_xkv", "e_wqkv", "e_wq", "e_wkv", "e_wm_g", "e_w1_g", "e_w2_g", "e_k", "e_v")] +
                 [("tail_exps", TailExpsT)])
 
 
@@ -41,7 +41,7 @@ class ModelT(C.Structure):
                 ("c2_w", C.c_void_p), ("c2_b", C.c_void_p), ("c4_w", C.c_void_p), ("c4_b", C.c_void_p),
                 ("stem_tgt_layers_host", C.POINTER(LayerT)), ("gemm_split", C.c_int32),
                 ("e_c0x", C.c_int32), ("e_c0w", C.c_int32), ("e_c2x", C.c_int32), ("e_c2w", C.c_int32),
-                ("wkv_cross", C.c_void_p), ("e_wkv_cross", C.c_int32)]
+                ("wkv_cross", C.c_void_p), ("e_wkv_cross", C.c_int32), ("e_k_cross", C.c_int32), ("e_v_cross", C.c_int32)]
 
 
 class BatchT(C.Structure):
@@ -60,7 +60,7 @@ SIGNATURES = {
     "scream_kv_finalize": (C.c_int, [V, V, V, I64, I32, I32, V, V]),
     "scream_pack_w_split": (C.c_int, [V, I32, I32, I32, I32, V, V]),
     "scream_gemm_split_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, I32, V, V, I64, V, V, I32, I32, I32, I32, V]),
-    "scream_gemm_qkv_split_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, V, V, V, I64, V, I32, I32, I32, I32, V]),
+    "scream_gemm_qkv_split_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, V, V, V, I64, V, I32, I32, I32, I32, I32, I32, V]),
     "scream_tail_image_bytes": (C.c_int64, [I32]),
     "scream_kv_image_bytes": (C.c_int64, []),
     "scream_pack_tail": (C.c_int, [V, V, V, I32, C.POINTER(TailExpsT), V, V]),

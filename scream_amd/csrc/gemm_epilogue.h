@@ -3,6 +3,7 @@
 // 32x32 MFMA layout: acc[tn][e] = C[row = mfma32_row(e, half)][col = tn*32 + r].
 #pragma once
 #include "common.h"
+#include "split.h"
 
 namespace {
 
@@ -25,6 +26,9 @@ struct EpiArgs {
     // SCREAM_EPI_QKV with more than one key/value tile PAIR (the cross stage's six target-side projections as one GEMM,
     // N = n_act + 512 L): floats between the partial arrays of consecutive layers
     int64_t kv_layer_stride;
+    // KV_H2 (the fp16 splits of gemm_split.hip): 2^k_exp, 2^v_exp and 2^-(k_exp + v_exp) -- the K^T V reduction runs on fp16 x 2
+    // planes of K' = elu(k) + 1 and V (|K'| 2^k_exp, |V| 2^v_exp <= 2^15: bounds of the projections, scream_amd/scales.py)
+    float kv_sk, kv_sv, kv_inv;
 };
 
 constexpr int KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;
@@ -40,7 +44,7 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 
 // NWAVES waves stacked in M (wave w owns rows w*32 .. w*32+31 of the block tile at packed-GEMM row m0);
 // slabs: LDS scratch of max(NWAVES * 8 * 256, 8 * KV_ELEMS) floats that no other wave-group touches meanwhile.
-template <int EPI, int NWAVES>
+template <int EPI, int NWAVES, bool KV_H2 = false>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[8], float* slabs, int wave, int lane, int tid,
                                               bool rows_exist, int64_t m0_cur, int n0_cur, const EpiArgs& ep,
                                               float* __restrict__ C, int64_t ldc) {
@@ -75,13 +79,33 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[8], float* slabs, in
 #pragma unroll
                 for (int e = 0; e < 16; ++e) kv[e] = 0.f;
                 float ks = 0.f;
+                if (KV_H2) {
+                    // Round 3: the same sum on the fp16 matrix cores.  Registers 8 s .. 8 s + 7 of the two tiles are the 16-token
+                    // step s of the contraction (both operands walk the tokens the same way), K' and V go in as two fp16 planes
+                    // each with their exponents, three products per step: 6 MFMAs of 32 cycles per head instead of 16 of 64
+                    // (a third on top of a key/value tile's main product once that had halved).
+                    f16x8 kp[2][2], vp[2][2];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float a = acc[hq][e];
-                    a = a > 0.f ? a + 1.0f : expf(a);                  // elu(k) + 1
-                    if (mfma32_row(e, half) >= valid_w) a = 0.f;       // padding rows do not exist
-                    kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[4 + hq][e], kv, 0, 0, 0);  // (1 / v_length is applied once, in scream_kv_finalize)
-                    ks += a;
+                    for (int e = 0; e < 16; ++e) {
+                        float a = acc[hq][e];
+                        a = a > 0.f ? a + 1.0f : expf(a);                  // elu(k) + 1
+                        if (mfma32_row(e, half) >= valid_w) a = 0.f;       // padding rows do not exist
+                        ks += a;
+                        SplitH2::split1(a * ep.kv_sk, e & 7, kp[e >> 3]);
+                        SplitH2::split1(acc[4 + hq][e] * ep.kv_sv, e & 7, vp[e >> 3]);
+                    }
+                    SplitH2::products(kv, kp[0], vp[0], kv);
+                    SplitH2::products(kv, kp[1], vp[1], kv);
+                    kv *= ep.kv_inv;  // exact: a power of two  (1 / v_length is applied once, in scream_kv_finalize)
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float a = acc[hq][e];
+                        a = a > 0.f ? a + 1.0f : expf(a);                  // elu(k) + 1
+                        if (mfma32_row(e, half) >= valid_w) a = 0.f;       // padding rows do not exist
+                        kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[4 + hq][e], kv, 0, 0, 0);  // (1 / v_length is applied once, in scream_kv_finalize)
+                        ks += a;
+                    }
                 }
                 ks += __shfl_xor(ks, 32);
                 float* sw = slabs + ((grp * HPR + hh2) * 4 + wg) * KV_ELEMS;

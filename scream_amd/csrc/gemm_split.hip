@@ -359,7 +359,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_split_kernel(const float* __
                         }
                 }
             } else {
-                gemm_epilogue<EPI, XWAVES>(acc, slabs, wave, lane, tid, rows_cur, m0_cur, n0_cur, ep, C, ldc);
+                gemm_epilogue<EPI, XWAVES, SP::SCALED>(acc, slabs, wave, lane, tid, rows_cur, m0_cur, n0_cur, ep, C, ldc);
             }
         }
         STAMP(2);
@@ -493,10 +493,11 @@ extern "C" int scream_gemm_qkv_split_f32(const float* A, int64_t lda, const void
                                          int32_t N, int32_t K, int32_t n_q, const int32_t* tile_cloud,
                                          const int32_t* cloud_row0, const int32_t* cloud_len, int64_t row_base,
                                          float* kv_partial, int32_t layout, int32_t split, int32_t a_exp, int32_t w_exp,
-                                         void* stream) {
+                                         int32_t k_exp, int32_t v_exp, void* stream) {
     SCREAM_REQUIRE(A && W_packed && kv_partial && tile_cloud && cloud_row0 && cloud_len, SCREAM_EINVAL);
     const SplitArgs sa{split, a_exp, w_exp};
     SCREAM_REQUIRE(split_args_ok(sa), SCREAM_EINVAL);
+    SCREAM_REQUIRE(split == SCREAM_SPLIT_BF3 || (k_exp >= -40 && k_exp <= 40 && v_exp >= -40 && v_exp <= 40), SCREAM_EINVAL);
     SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0 && N > 0 && N % XBN == 0 && K >= 64 && K % 64 == 0 && (K / 32 - 2) % 3 == 0, SCREAM_EUNSUPPORTED);  // K = 64 + 192 j
     // N = n_q + 512 L: L key/value tile pairs; L > 1 (several layers' key/value projections of the same rows) only without queries
     SCREAM_REQUIRE((n_q == 0 || n_q == XBN) && N > n_q && (N - n_q) % (2 * XBN) == 0 && (n_q == 0 || N == n_q + 2 * XBN) && row_base >= 0 &&
@@ -507,6 +508,7 @@ extern "C" int scream_gemm_qkv_split_f32(const float* A, int64_t lda, const void
     SCREAM_REQUIRE(!(layout & SCREAM_LAYOUT_C_FRAG) || n_q == XBN, SCREAM_EUNSUPPORTED);
     if (int rc = check_layout(layout, lda, n_q ? ldq : SCREAM_D_MODEL, K, SCREAM_EPI_QKV, n_q ? n_q : SCREAM_D_MODEL)) return rc;
     EpiArgs ep{n_q, nullptr, nullptr, 0, nullptr, nullptr, kv_partial, tile_cloud, cloud_row0, cloud_len, row_base,
-               (layout & SCREAM_LAYOUT_C_FRAG) ? 1 : 0, (M / SCREAM_ROW_TILE) * SCREAM_NHEAD * (int64_t)KV_ELEMS};
+               (layout & SCREAM_LAYOUT_C_FRAG) ? 1 : 0, (M / SCREAM_ROW_TILE) * SCREAM_NHEAD * (int64_t)KV_ELEMS,
+               exp2i(k_exp), exp2i(v_exp), exp2i(-k_exp - v_exp)};
     return launch_split<SCREAM_EPI_QKV>(A, lda, W_packed, Q, ldq, M, N, K, ep, as_stream(stream), layout & SCREAM_LAYOUT_A_FRAG, sa);
 }

@@ -175,7 +175,7 @@ class PointTransformer(nn.Module):
             L.wq, L.e_wq = dev_mat(m.q_proj.weight)
             L.wkv, L.e_wkv = dev_mat(wkv)
             ex = scales.layer_exps(m, in_q, in_kv) if fp16_split else {}
-            L.e_xq, L.e_xkv = ex.get("e_xq", 0), ex.get("e_xkv", 0)
+            L.e_xq, L.e_xkv, L.e_k, L.e_v = ex.get("e_xq", 0), ex.get("e_xkv", 0), ex.get("e_k", 0), ex.get("e_v", 0)
             L.tail_exps = ops.tail_exps(**ex)
             L.tail = None
             if split and self.fused_tail:  # one launch for everything behind the projections (scream_layer_tail_f32)
@@ -210,6 +210,8 @@ class PointTransformer(nn.Module):
             stack = torch.cat([torch.cat([c.layer.k_proj.weight[:128], c.layer.v_proj.weight[:128], c.layer.k_proj.weight[128:],
                                           c.layer.v_proj.weight[128:]], dim=0) for c in cross], dim=0)
             mt.wkv_cross, mt.e_wkv_cross = dev_mat(stack)
+            cross_L = [layers[self.self_layer_num + 2 * j + 1] for j in range(self.cross_layer_num)]
+            mt.e_k_cross, mt.e_v_cross = min(L.e_k for L in cross_L), min(L.e_v for L in cross_L)  # one launch: the tightest
         if fp16_split:  # coor_mlp (models/pointnet.py:27-33): LayerNorm2 output -> Conv1d + bias, relu -> Conv1d
             mt.e_c0x = scales.exp_for(scales.ln_bound(*coor_in))
             mt.e_c2x = scales.exp_for(scales.lin_bound(c0w, *coor_in, bias=self.coor_mlp[0].bias))

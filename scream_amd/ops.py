@@ -64,6 +64,7 @@ class PackedW:
     w_exp: int
     N: int
     K: int
+    row_l1: Optional[torch.Tensor] = None  # [N] sum_k |W[n, k]| on the host: bounds |A W^T| by max|A| * row_l1 (gemm_qkv's K^T V exponents)
 
     def data_ptr(self) -> int:
         return self.data.data_ptr()
@@ -97,7 +98,7 @@ def pack_w(W: torch.Tensor, split: Optional[int] = None, w_exp: Optional[int] = 
     dt = torch.float16 if split in (SPLIT_H2, SPLIT_H1) else torch.bfloat16
     out = torch.empty(split, K // 32, N, 32, device=W.device, dtype=dt)
     check(_lib.load().scream_pack_w_split(_p(W), N, K, split, w_exp, _p(out, dt), _stream()), "scream_pack_w_split")
-    return PackedW(out, split, w_exp, N, K)
+    return PackedW(out, split, w_exp, N, K, W.abs().sum(dim=1).cpu() if split != SPLIT_BF3 else None)
 
 
 LAYOUT_A_FRAG, LAYOUT_C_FRAG = 1, 2
@@ -192,7 +193,7 @@ def layer_tail(Q: torch.Tensor, kv_image: torch.Tensor, tile_cloud, kv_cloud_off
 
 
 def gemm_qkv(A: torch.Tensor, W, n_q: int, tile_cloud, cloud_row0, cloud_len, row_base: int, layout: int = 0,
-             a_exp: Optional[int] = None):
+             a_exp: Optional[int] = None, k_exp: Optional[int] = None, v_exp: Optional[int] = None):
     """Fused q/k/v projection (scream_gemm_qkv_f32 / scream_gemm_qkv_split_f32 for W = pack_w(...)).  Returns
     (Q' [M,256] or None, kv_partial [M/128,8,1056]).  layout (split kernel only): LAYOUT_A_FRAG | LAYOUT_C_FRAG."""
     M, K = A.shape
@@ -204,7 +205,15 @@ def gemm_qkv(A: torch.Tensor, W, n_q: int, tile_cloud, cloud_row0, cloud_len, ro
     args = (_p(A), A.stride(0), W.data_ptr() if sp else _p(W), _p(Q), n_q, M, N, K, n_q,
             _p(tile_cloud, torch.int32), _p(cloud_row0, torch.int32), _p(cloud_len, torch.int32), row_base, _p(part))
     if sp:
-        check(_lib.load().scream_gemm_qkv_split_f32(*args, layout, W.split, _a_exp(A, W, a_exp), W.w_exp, _stream()),
+        if W.split != SPLIT_BF3 and (k_exp is None or v_exp is None):
+            # the K^T V epilogue's operands: |k|, |v| <= max|A| * (L1 norm of their weight rows); key rows are the first 128 of
+            # every 256 behind the queries (include/scream_hip.h).  Convenience default (a device sync), as for a_exp.
+            amax = float(A.abs().max().item())
+            rl = W.row_l1[n_q:].view(-1, 2, 128)
+            k_exp = scales.exp_for(1.0 + amax * float(rl[:, 0].max())) if k_exp is None else k_exp
+            v_exp = scales.exp_for(amax * float(rl[:, 1].max())) if v_exp is None else v_exp
+        check(_lib.load().scream_gemm_qkv_split_f32(*args, layout, W.split, _a_exp(A, W, a_exp), W.w_exp, int(k_exp or 0),
+                                                    int(v_exp or 0), _stream()),
               "scream_gemm_qkv_split_f32")
     else:
         assert layout == 0

@@ -72,5 +72,7 @@ def layer_exps(m, in_q, in_kv) -> Dict[str, int]:
     """Exponents of one MHAttention block.  m: parameter holder (q_proj, k_proj, v_proj, merge, mlp, norm1, norm2);
     in_q / in_kv: (gamma, beta) of the LayerNorm that produced the query-side / key-value-side input."""
     ex = tail_exps(m.merge.weight, m.mlp[0].weight, m.mlp[2].weight, m.norm1.weight, m.norm1.bias, lin_bound(m.v_proj.weight, *in_kv))
-    ex.update(e_xq=exp_for(ln_bound(*in_q)), e_xkv=exp_for(ln_bound(*in_kv)))
+    ex.update(e_xq=exp_for(ln_bound(*in_q)), e_xkv=exp_for(ln_bound(*in_kv)),
+              # the projection's K^T V epilogue: K' = elu(k) + 1 <= 1 + max(k, 0), V = v
+              e_k=exp_for(1.0 + lin_bound(m.k_proj.weight, *in_kv)), e_v=exp_for(lin_bound(m.v_proj.weight, *in_kv)))
     return ex
