@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SCREAM_LIB=<path>: load that build instead (A/B runs of two builds on the same GPU box; never built automatically)
 LIB_PATH = os.environ.get("SCREAM_LIB") or os.path.join(_HERE, "libscream_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)

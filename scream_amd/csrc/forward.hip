@@ -212,8 +212,8 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
 
 }  // namespace
 
-extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi11"; }
-extern "C" int scream_abi_version(void) { return 11; }
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi12"; }
+extern "C" int scream_abi_version(void) { return 12; }
 
 extern "C" void* scream_trace_create(int32_t capacity) {
     if (capacity <= 0) return nullptr;
