@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
 from typing import Callable, Iterable, List, Optional, Sequence
 
 import numpy as np
@@ -102,6 +103,10 @@ def aggregate_rows(rows: np.ndarray, re_static_method: str = "median"):
 
 
 _staging = {}  # (device, lane stream) -> StagingBuffers
+# Batches evaluate_loader keeps enqueued, one stream each.  Measured end to end with the GPU ICP on (tools/eval_e2e.py, 4 096 pairs,
+# profiles/r03_eval_e2e.txt): 2 -> 1 366 pairs/s, 3 -> 1 510, 4 -> 1 535, 6 -> 1 564 (without ICP 1 512 / 1 665 / 1 618 / 1 664): with two, the
+# device ran one batch alone whenever the host was collecting the other.  Each costs one forward workspace and one staging set.
+IN_FLIGHT = int(os.environ.get("SCREAM_IN_FLIGHT", "4"))
 
 
 def _register_lane(net, its, centers, pair_ids, corr, dis_thresh, icp, icp_dist, icp_iters, device, pred_hook):
@@ -243,7 +248,7 @@ def evaluate_items(net, items: Sequence[tuple], pair_ids: Sequence[int], corr: s
 def evaluate_loader(net, loader: Iterable, corr: str = "tgt", dis_thresh: float = 0.1,
                     re_static_method: str = "median", batch_pairs: int = 32, icp="gpu",
                     verbose: bool = True, pred_hook: Optional[Callable] = None, num_workers: int = 0,
-                    worker_context: Optional[str] = None):
+                    worker_context: Optional[str] = None, in_flight: int = IN_FLIGHT):
     """evaluate_3d_match.py:53-171.  ``loader`` is a dataset or DataLoader of the reference's 9-tuples.
     ``icp="gpu"`` (default) refines every pose like evaluate_3d_match.py:106-119 does; ``icp=None`` skips it.
     With torch.distributed initialised the pairs are sharded round-robin over ranks and the per-pair rows
@@ -278,24 +283,27 @@ def evaluate_loader(net, loader: Iterable, corr: str = "tgt", dis_thresh: float 
                 float(np.concatenate(rows)[:, sdist.COL_SUCCESS].mean())), end="")
 
     # Batch i is enqueued before the host side of batch i-1 runs: the GPU never waits for the host.  Consecutive batches go to
-    # two alternating HIP streams, each batch whole (one packed forward of all its pairs): two batches are then in flight
+    # alternating HIP streams, each batch whole (one packed forward of all its pairs): several batches are then in flight
     # out of phase, and the launch-bound end of one -- the ICP loop is ~60 tiny dependent launches -- runs beside the
-    # other's forward instead of beside nothing (two lanes INSIDE a batch finish together and both sit in their ICP loops
+    # others' forwards instead of beside nothing (two lanes INSIDE a batch finish together and both sit in their ICP loops
     # at the same time: 1 373 vs 1 570 pairs/s with / without ICP; results are the same either way, pairs never interact).
     dev = next(net.parameters()).device if hasattr(net, "parameters") else None
-    streams = _lanes.lane_streams(dev, 2) if dev is not None and dev.type == "cuda" else [None, None]
-    pending, k = None, 0
+    # in_flight batches are enqueued before the oldest is collected, each on its own stream (a stream, its staging buffers and
+    # its workspace are reused only after the batch that last used them has been collected).
+    in_flight = max(2, int(in_flight))
+    streams = _lanes.lane_streams(dev, in_flight) if dev is not None and dev.type == "cuda" else [None] * in_flight
+    pending, k = [], 0
     for items in batches:
         items = unpack_batch(items)  # (worker processes send a batch as three flat tensors, scream_amd/data.py)
         ids = mine[done:done + len(items)]
-        fin = evaluate_items_async(net, items, ids, corr, dis_thresh, icp, pred_hook=pred_hook, stream=streams[k % 2])
+        fin = evaluate_items_async(net, items, ids, corr, dis_thresh, icp, pred_hook=pred_hook, stream=streams[k % in_flight])
         k += 1
-        if pending is not None:
-            collect(*pending)
         done += len(ids)
-        pending = (fin, done)
-    if pending is not None:
-        collect(*pending)
+        pending.append((fin, done))
+        if len(pending) >= in_flight:
+            collect(*pending.pop(0))
+    for pd in pending:
+        collect(*pd)
     local = np.concatenate(rows) if rows else np.zeros((0, sdist.ROW_WIDTH))
     allrows = sdist.all_gather_rows(local)
     out = aggregate_rows(allrows, re_static_method)

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--gen-procs", type=int, default=14, help="1 = generate in-process (e.g. under rocprofv3)")
     ap.add_argument("--workers", default="0,2,4,8,12")
     ap.add_argument("--torch-threads", type=int, default=0, help="torch.set_num_threads() of the main process (0 = leave)")
+    ap.add_argument("--in-flight", default="4", help="batches kept enqueued (comma list: legs 1-2 are run for each)")
     ap.add_argument("--worker-context", default=None, help="multiprocessing context of the loader workers (fork | spawn | forkserver)")
     args = ap.parse_args()
     D = min(args.distinct, args.n)
@@ -94,8 +95,10 @@ def main():
         print("%-46s %5d pairs in %6.2f s -> %7.1f pairs/s  (steady %7.1f, start-up %.2f s)   (loss, rre, rte, rr) = %s"
               % (tag, len(ds), dt, len(ds) / dt, steady, first[0][0] - t0, tuple(round(float(v), 4) for v in out)), flush=True)
         return steady, out
-    leg("1. in-memory, icp=None", Mem(), icp=None)
-    mem_rate, mem_out = leg("2. in-memory, icp='gpu' (reference default)", Mem(), icp="gpu")
+    flights = [int(v) for v in args.in_flight.split(",")]
+    for nf in flights[::-1]:  # (the first of the list last: it is the one the from-files legs are compared with)
+        leg("1. in-memory, icp=None, in_flight=%d" % nf, Mem(), icp=None, in_flight=nf)
+        mem_rate, mem_out = leg("2. in-memory, icp='gpu' (reference default), in_flight=%d" % nf, Mem(), icp="gpu", in_flight=nf)
 
     with tempfile.TemporaryDirectory() as root:  # the reference's on-disk layout, process_3d_match.py:38-40,199-200
         os.makedirs(os.path.join(root, "info"))
@@ -110,7 +113,7 @@ def main():
         best = None
         for k in [int(v) for v in args.workers.split(",")]:
             rate, out = leg("3. from files, icp='gpu', num_workers=%d%s" % (k, " (%s)" % args.worker_context if args.worker_context and k else ""),
-                            CycledFiles(root, args.n, D), icp="gpu", num_workers=k, worker_context=args.worker_context)
+                            CycledFiles(root, args.n, D), icp="gpu", num_workers=k, worker_context=args.worker_context, in_flight=flights[0])
             assert all(abs(float(a) - float(b)) < 1e-9 for a, b in zip(out, mem_out)), "from-files results differ from in-memory"
             if best is None and rate >= 0.95 * mem_rate:
                 best = k
