@@ -16,8 +16,9 @@ Extra objects on that line:
   roofline     -- the GEMM kernel (all epilogue instantiations pooled; per-instantiation rows in "by_kernel" so
                   they can be matched against profiles/*kernel_stats*): algorithmic fp32 flops (true, unpadded
                   token counts) / the time during which a GEMM launch was running, measured live with HIP events
-                  on the launch streams inside the timed region (scream_trace_*).  The step's pairs run as two
-                  concurrent lanes, so launches overlap: that time is the union of the launch intervals
+                  on the launch streams inside the timed region (scream_trace_*).  Consecutive steps run WHOLE on two
+                  alternating HIP streams (config.steps_in_flight = 2; round 3 -- rounds 1-2 split every step into two
+                  concurrent lanes, --lanes 2), so launches of two steps overlap: that time is the union of the launch intervals
                   ("busy_ms_per_step"; "summed_launch_ms_per_step" and the per-launch avg_ms rows count overlapped
                   time twice and are what rocprofv3's per-kernel durations add up to; --lanes 1 makes them equal).  Peak
                   (MI355X_MICROARCH.md: 2500 TFLOP/s dense for bf16 and fp16 alike): SCREAM_GEMM=h2 (default) runs the split
@@ -220,7 +221,13 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per step per GPU")
-    ap.add_argument("--lanes", type=int, default=2, help="concurrent sub-batches of the step's pairs (scream_amd/lanes.py)")
+    ap.add_argument("--alternate", type=int, default=None,
+                    help="N > 0: every step runs WHOLE on one of N HIP streams in turn (N steps in flight, out of phase).  The default "
+                         "(2) unless --lanes is given: 1 686 pairs/s against 1 639 for --lanes 2 on the same box, "
+                         "profiles/r03_bench_alternate_vs_lanes.txt")
+    ap.add_argument("--lanes", type=int, default=None,
+                    help="split every step's pairs into this many concurrent sub-batches that start together (scream_amd/lanes.py; "
+                         "rounds 1-2's default was 2); --lanes 1 = one step at a time on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sustain", dest="sustain", action="store_false", help="skip the >= 3 s sustained-rate leg")
     ap.add_argument("--no-power", action="store_true",
@@ -288,8 +295,10 @@ def main():
     net.load_state_dict(sd)
     net = net.to(dev).eval()
 
-    # The step's pairs run as concurrent lanes (scream_amd/lanes.py): independent sub-batches on their own HIP streams
-    # whose kernels fill each other's partial last rounds and store-bound epilogues.  Inputs are resident per lane.
+    # Default (--alternate 2): consecutive steps run whole on two alternating HIP streams, so two steps are in flight OUT OF
+    # PHASE -- one's power-cap-bound layer tails beside the other's projections, each filling the other's partial last rounds.
+    # --lanes L (rounds 1-2): the step's pairs as L concurrent sub-batches (scream_amd/lanes.py) that start together and join
+    # at the step's end.  Inputs are resident per lane.
     class Lane:
         def __init__(self, its):
             self.batch = PackedBatch.from_pairs([it[0].to(dev) for it in its], [it[1].to(dev) for it in its],
@@ -307,7 +316,13 @@ def main():
                     rng.normal(scale=0.01 * it[4], size=it[0].shape).astype(np.float32))
             self.reg_pred = reg.to(dev)
 
+    if args.alternate is None:
+        args.alternate = 2 if args.lanes is None else 0
+    if args.alternate > 0 or args.lanes is None:
+        args.lanes = 1
     lane_parts = [Lane([items[i] for i in rg]) for rg in lanes.split_weighted([it[0].shape[0] + it[1].shape[0] for it in items], args.lanes)]
+    alt_streams = lanes.lane_streams(dev, args.alternate) if args.alternate > 0 else []
+    step_no = [0]
     src_len = [n for ln in lane_parts for n in ln.batch.src_len]
     tgt_len = [n for ln in lane_parts for n in ln.batch.tgt_len]
     rows_total = sum(ln.batch.rows_total for ln in lane_parts)
@@ -325,6 +340,14 @@ def main():
         return re, te, n_corr
 
     def step(trace=None, registered=False):
+        if alt_streams:  # the whole step on the next stream; nothing joins until fence()
+            st = alt_streams[step_no[0] % len(alt_streams)]
+            step_no[0] += 1
+            with torch.cuda.stream(st):
+                return step_on_current(trace, registered)
+        return step_on_current(trace, registered)
+
+    def step_on_current(trace=None, registered=False):
         outs = lanes.run(dev, lane_parts, lambda ln: lane_step(ln, trace, registered))
         re, te, n_corr = (torch.cat([o[i] for o in outs]) for i in range(3))
         if world > 1:  # the path's only exchange: per-pair metric rows
@@ -341,7 +364,10 @@ def main():
     first = None
     for _ in range(args.warmup):
         o = step()
-        first = first if first is not None else tuple(t.clone() for t in o)
+        if first is None:
+            if alt_streams:
+                torch.cuda.synchronize()  # the step ran on a side stream
+            first = tuple(t.clone() for t in o)
     cap = 200 * len(lane_parts) * max(args.steps, 1)  # ~135 records per forward
     trace = lib.scream_trace_create(cap)
     assert trace, "scream_trace_create failed"
@@ -520,7 +546,7 @@ def main():
                                     "uniform64k": "BASELINE configs[4]: 65 536 uniform points per cloud"}[args.workload]
                                    + ", batch-of-pairs=%d per GPU, A1-A10 per pair (forward 6+6 layers d_model 256, 1-NN thresh %g, "
                                      "Kabsch, RE/TE), random-init weights seed 0" % (B, dis_thresh),
-                       "pairs_per_step_per_gpu": B, "lanes": len(lane_parts), "mean_src_points": round(float(np.mean(src_len)), 1),
+                       "pairs_per_step_per_gpu": B, "lanes": len(lane_parts), "steps_in_flight": max(1, args.alternate), "mean_src_points": round(float(np.mean(src_len)), 1),
                        "mean_tgt_points": round(float(np.mean(tgt_len)), 1), "parallelism": "dp%d (pairs sharded, metric-row all-gather)" % world,
                        "rccl_ranks": tdist.get_world_size() if world > 1 else 1, "collective_backend": backend if world > 1 else None,
                        "gemm_backend": net.gemm_backend},
