@@ -178,6 +178,11 @@ int scream_pe_embed_ln(const float* xyz, const int32_t* tile_cloud, const float*
                        const float* dim_t, const float* emb_w, const float* emb_b,
                        const float* gamma, const float* beta, float* feats, int64_t rows,
                        void* stream);
+/* the same values written FRAGMENT-major (SCREAM_ACT_FRAG below): what the fused forward feeds its first projection */
+int scream_pe_embed_ln_frag(const float* xyz, const int32_t* tile_cloud, const float* center,
+                            const float* dim_t, const float* emb_w, const float* emb_b,
+                            const float* gamma, const float* beta, float* feats, int64_t rows,
+                            void* stream);
 
 /* ---- A3 (reduce): per key cloud and head, KV = sum_s K[s]^T (V[s]/S), Ksum = sum_s K[s]
  * Replaces models/transformer.py:38-41 (values / v_length, the "nshd,nshv->nhdv" einsum, K.sum).

@@ -68,6 +68,7 @@ SIGNATURES = {
     "scream_layer_tail_f32": (C.c_int, [V, V, V, I32, V, V, V, V, V, V, V, V, I64, I32, C.POINTER(TailExpsT), V]),
     "scream_act_layout": (C.c_int, [V, V, I64, I32, V]),
     "scream_pe_embed_ln": (C.c_int, [V, V, V, V, V, V, V, V, V, I64, V]),
+    "scream_pe_embed_ln_frag": (C.c_int, [V, V, V, V, V, V, V, V, V, I64, V]),
     "scream_kv_reduce": (C.c_int, [V, V, I64, I64, V, V, I32, I32, I32, V, V, V]),
     "scream_attn_apply": (C.c_int, [V, I64, V, V, I32, V, V, I64, I64, V]),
     "scream_coor_head": (C.c_int, [V, V, V, V, I64, V]),

@@ -12,6 +12,10 @@ constexpr int NPF = 84;  // num_pos_feats = 256 // 3 // 2 * 2 (models/transforme
 // feats[row] = LN(pe(xyz[row]) + W_e (xyz[row] - center[cloud]) + b_e); models/pointnet.py:45-48.
 // Feature f < 252: axis a = f / 84, i = f % 84, value sin(p) for even i, cos(p) for odd i with
 // p = (x_a * 2 pi) / dim_t[i] (models/transformer.py:172-176); features 252..255 are the zero pad (:179).
+// One block = one 32-row group, eight rows per wave.  FRAG: the group goes out FRAGMENT-major (SCREAM_ACT_FRAG,
+// include/scream_hip.h) through an LDS tile -- the layout the split GEMM and the layer tail read, which used to cost a separate
+// scream_act_layout pass over the features (118 us per step); the values are the row-major kernel's, bit for bit.
+template <bool FRAG>
 __global__ __launch_bounds__(256) void pe_embed_ln_kernel(const float* __restrict__ xyz,
                                                          const int32_t* __restrict__ tile_cloud,
                                                          const float* __restrict__ center,
@@ -20,42 +24,75 @@ __global__ __launch_bounds__(256) void pe_embed_ln_kernel(const float* __restric
                                                          const float* __restrict__ emb_b,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
-                                                         float* __restrict__ feats, int64_t rows) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float x[3] = {xyz[row * 3 + 0], xyz[row * 3 + 1], xyz[row * 3 + 2]};
-    const int cloud = tile_cloud[row / SCREAM_ROW_TILE];
-    const float xe[3] = {x[0] - center[cloud * 3 + 0], x[1] - center[cloud * 3 + 1], x[2] - center[cloud * 3 + 2]};
+                                                         float* __restrict__ feats) {
+    constexpr int LDT = D + 4;  // row stride of the tile: 16-byte aligned, rows 4 banks apart
+    __shared__ __attribute__((aligned(16))) float tile[FRAG ? 32 * LDT : 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int cloud = tile_cloud[row0 / SCREAM_ROW_TILE];
+    const float c[3] = {center[cloud * 3 + 0], center[cloud * 3 + 1], center[cloud * 3 + 2]};
     const float two_pi = 6.283185307179586f;  // fp32(1.0 * 2 * math.pi), transformer.py:155,171
-
-    float v[4];
-    float s = 0.f;
+    float ew[4][3], eb[4], g[4], be[4], dt[4];
+    int ax[4];
+    bool odd[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int f = lane + 64 * k;
-        float pe = 0.f;
-        if (f < 3 * NPF) {
-            const int a = f / NPF, i = f - a * NPF;
-            const float p = (x[a] * two_pi) / dim_t[i];
-            pe = (i & 1) ? cosf(p) : sinf(p);
+        ew[k][0] = emb_w[f * 3 + 0];
+        ew[k][1] = emb_w[f * 3 + 1];
+        ew[k][2] = emb_w[f * 3 + 2];
+        eb[k] = emb_b[f];
+        g[k] = gamma[f];
+        be[k] = beta[f];
+        ax[k] = f < 3 * NPF ? f / NPF : -1;
+        const int i = f < 3 * NPF ? f - ax[k] * NPF : 0;
+        dt[k] = dim_t[i];
+        odd[k] = i & 1;
+    }
+    for (int rr = 0; rr < 8; ++rr) {
+        const int rl = wave * 8 + rr;
+        const int64_t row = row0 + rl;
+        const float x[3] = {xyz[row * 3 + 0], xyz[row * 3 + 1], xyz[row * 3 + 2]};
+        const float xe[3] = {x[0] - c[0], x[1] - c[1], x[2] - c[2]};
+        float v[4];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float pe = 0.f;
+            if (ax[k] >= 0) {
+                const float p = ((ax[k] == 0 ? x[0] : ax[k] == 1 ? x[1] : x[2]) * two_pi) / dt[k];
+                pe = odd[k] ? cosf(p) : sinf(p);
+            }
+            const float e = ew[k][0] * xe[0] + ew[k][1] * xe[1] + ew[k][2] * xe[2] + eb[k];
+            v[k] = pe + e;
+            s += v[k];
         }
-        const float e = emb_w[f * 3 + 0] * xe[0] + emb_w[f * 3 + 1] * xe[1] + emb_w[f * 3 + 2] * xe[2] + emb_b[f];
-        v[k] = pe + e;
-        s += v[k];
-    }
-    const float mean = wave_sum(s) * (1.0f / D);
-    float q = 0.f;
+        const float mean = wave_sum(s) * (1.0f / D);
+        float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float d = v[k] - mean;
-        q += d * d;
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+        for (int k = 0; k < 4; ++k) {
+            const float d = v[k] - mean;
+            q += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int f = lane + 64 * k;
-        feats[row * D + f] = (v[k] - mean) * rstd * gamma[f] + beta[f];
+        for (int k = 0; k < 4; ++k) {
+            const int f = lane + 64 * k;
+            const float o = (v[k] - mean) * rstd * g[k] + be[k];
+            if (FRAG) tile[rl * LDT + f] = o;
+            else feats[row * D + f] = o;
+        }
+    }
+    if (FRAG) {
+        __syncthreads();
+        // float4 q of the group = [segment of 8 features q >> 6][lane (r, half) = q & 63]: features 8 seg + 4 half .. + 3 of row r
+        float* out = feats + row0 * D;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = threadIdx.x + 256 * i;
+            const int seg = q >> 6, l = q & 63, r = l & 31, half = l >> 5;
+            *reinterpret_cast<f32x4*>(out + q * 4) = *reinterpret_cast<const f32x4*>(&tile[r * LDT + seg * 8 + 4 * half]);
+        }
     }
 }
 
@@ -88,18 +125,37 @@ __global__ __launch_bounds__(256) void coor_head_kernel(const float* __restrict_
 
 }  // namespace
 
+namespace {
+int pe_embed_ln_launch(const float* xyz, const int32_t* tile_cloud, const float* center, const float* dim_t, const float* emb_w,
+                       const float* emb_b, const float* gamma, const float* beta, float* feats, int64_t rows, bool frag,
+                       void* stream) {
+    SCREAM_REQUIRE(xyz && tile_cloud && center && dim_t && emb_w && emb_b && gamma && beta && feats, SCREAM_EINVAL);
+    SCREAM_REQUIRE(rows >= 0 && rows % SCREAM_ROW_TILE == 0, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(feats) & 15) == 0, SCREAM_EINVAL);
+    if (rows == 0) return 0;
+    const int64_t blocks = rows / 32;
+    SCREAM_REQUIRE(blocks < (1ll << 31), SCREAM_EUNSUPPORTED);
+    if (frag)
+        pe_embed_ln_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(xyz, tile_cloud, center, dim_t, emb_w, emb_b,
+                                                                                           gamma, beta, feats);
+    else
+        pe_embed_ln_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(xyz, tile_cloud, center, dim_t, emb_w, emb_b,
+                                                                                            gamma, beta, feats);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+
 extern "C" int scream_pe_embed_ln(const float* xyz, const int32_t* tile_cloud, const float* center,
                                   const float* dim_t, const float* emb_w, const float* emb_b, const float* gamma,
                                   const float* beta, float* feats, int64_t rows, void* stream) {
-    SCREAM_REQUIRE(xyz && tile_cloud && center && dim_t && emb_w && emb_b && gamma && beta && feats, SCREAM_EINVAL);
-    SCREAM_REQUIRE(rows >= 0 && rows % SCREAM_ROW_TILE == 0, SCREAM_EUNSUPPORTED);
-    if (rows == 0) return 0;
-    const int64_t blocks = rows / 4;
-    SCREAM_REQUIRE(blocks < (1ll << 31), SCREAM_EUNSUPPORTED);
-    pe_embed_ln_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(
-        xyz, tile_cloud, center, dim_t, emb_w, emb_b, gamma, beta, feats, rows);
-    SCREAM_LAUNCH_CHECK();
-    return 0;
+    return pe_embed_ln_launch(xyz, tile_cloud, center, dim_t, emb_w, emb_b, gamma, beta, feats, rows, false, stream);
+}
+
+extern "C" int scream_pe_embed_ln_frag(const float* xyz, const int32_t* tile_cloud, const float* center,
+                                       const float* dim_t, const float* emb_w, const float* emb_b, const float* gamma,
+                                       const float* beta, float* feats, int64_t rows, void* stream) {
+    return pe_embed_ln_launch(xyz, tile_cloud, center, dim_t, emb_w, emb_b, gamma, beta, feats, rows, true, stream);
 }
 
 extern "C" int scream_coor_head(const float* X, const float* W, const float* b, float* out, int64_t rows,

@@ -303,9 +303,10 @@ extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t*
     const int64_t rs = b.rows_src, ra = b.rows_total;
     {
         Scope sc(c.tr, TR_EMBED, ra, 0, 0, stream);
-        TRY(scream_pe_embed_ln(b.xyz, b.tile_cloud, b.center, m.dim_t, m.emb_w, m.emb_b, m.pre_g, m.pre_b, c.frag ? w.x1 : w.x0, ra,
-                               stream));
-        if (c.frag) TRY(scream_act_layout(w.x1, w.x0, ra, 1, stream));
+        if (c.frag)  // straight into the layout the projections and the layer tail read
+            TRY(scream_pe_embed_ln_frag(b.xyz, b.tile_cloud, b.center, m.dim_t, m.emb_w, m.emb_b, m.pre_g, m.pre_b, w.x0, ra, stream));
+        else
+            TRY(scream_pe_embed_ln(b.xyz, b.tile_cloud, b.center, m.dim_t, m.emb_w, m.emb_b, m.pre_g, m.pre_b, w.x0, ra, stream));
     }
     float* cur = w.x0;
     float* nxt = w.x1;

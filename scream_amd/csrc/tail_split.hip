@@ -722,37 +722,47 @@ __global__ void pack_tail_kernel(const float* __restrict__ Wm, const float* __re
     for (int pl = 0; pl < SP::NP; ++pl) out[(((int64_t)stage * SP::NP + pl) * 16 + frag) * 64 + lane] = p[pl];
 }
 
+constexpr int KVF_THREADS = 320;  // kv_finalize_x3_kernel: 264 threads x 4 consecutive elements = the 1 056 of a head
+
 // Sum of the per-128-row-tile K^T V partials of the fused q/k/v GEMM (as kv_finalize_tiles_kernel, attention.hip) written
 // as the operand image of tail_kernel: per cloud and head the A-operand fragments of KV_h^T / S (row m = value index
 // v, contraction index d = chunk_k(step, half, j)) in three bf16 planes, then Ksum as fp32.  grid (n_kv * 8, n_layers),
-// block 1024; layer l reads partial + l * partial_layer_stride floats and writes kvimg + l * image_layer_stride bytes.
-__global__ __launch_bounds__(1024) void kv_finalize_x3_kernel(const float* __restrict__ partial,
-                                                            const int32_t* __restrict__ cloud_row0,
-                                                            const int32_t* __restrict__ cloud_len, int64_t row_base,
-                                                            int cloud_begin, char* __restrict__ kvimg,
-                                                            int64_t partial_layer_stride, int64_t image_layer_stride) {
+// block KVF_THREADS; layer l reads partial + l * partial_layer_stride floats and writes kvimg + l * image_layer_stride bytes.
+__global__ __launch_bounds__(KVF_THREADS) void kv_finalize_x3_kernel(const float* __restrict__ partial,
+                                                                   const int32_t* __restrict__ cloud_row0,
+                                                                   const int32_t* __restrict__ cloud_len, int64_t row_base,
+                                                                   int cloud_begin, char* __restrict__ kvimg,
+                                                                   int64_t partial_layer_stride, int64_t image_layer_stride) {
     constexpr int KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;
+    static_assert(KV_ELEMS % 4 == 0 && KV_ELEMS / 4 <= KVF_THREADS, "");
+    // ONE pass, four consecutive elements per thread (264 of the 320 threads): with 1024 threads and one element each, the 32
+    // Ksum elements cost a second trip through the whole reduction for half a wave -- the launch is latency, not bandwidth.
+    const int i4 = threadIdx.x;
+    if (i4 >= KV_ELEMS / 4) return;
     const int kvi = blockIdx.x / SCREAM_NHEAD, h = blockIdx.x % SCREAM_NHEAD;
     const int cloud = cloud_begin + kvi;
     partial += (int64_t)blockIdx.y * partial_layer_stride;
     kvimg += (int64_t)blockIdx.y * image_layer_stride;
     const int t0 = (int)((cloud_row0[cloud] - row_base) / SCREAM_ROW_TILE);
     const int nt = (cloud_len[cloud] + SCREAM_ROW_TILE - 1) / SCREAM_ROW_TILE;
-    const float* p = partial + ((int64_t)t0 * SCREAM_NHEAD + h) * KV_ELEMS;
+    const float* p = partial + ((int64_t)t0 * SCREAM_NHEAD + h) * KV_ELEMS + 4 * i4;
     char* img = kvimg + (size_t)cloud * KV_IMAGE_BYTES;
     const float S = (float)cloud_len[cloud];
-    for (int i = threadIdx.x; i < KV_ELEMS; i += 1024) {
-        float s8[16];  // sixteen chains in a fixed combination order: deterministic (same order as kv_finalize_tiles_kernel)
+    f32x4 s8[16];  // sixteen chains in a fixed combination order: deterministic (same order as kv_finalize_tiles_kernel)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s8[u] = 0.f;
-        for (int c = 0; c < nt; c += 16) {
+    for (int u = 0; u < 16; ++u) s8[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nt; c += 16) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (c + u < nt) s8[u] += p[(int64_t)(c + u) * SCREAM_NHEAD * KV_ELEMS + i];
-        }
+        for (int u = 0; u < 16; ++u)
+            if (c + u < nt) s8[u] += *reinterpret_cast<const f32x4*>(p + (int64_t)(c + u) * SCREAM_NHEAD * KV_ELEMS);
+    }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s8[u] += s8[u + 8];
-        const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    for (int u = 0; u < 8; ++u) s8[u] += s8[u + 8];
+    const f32x4 s4 = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = 4 * i4 + e;
+        const float s = s4[e];
         if (i < 32 * 32) {
             const int d = i >> 5, v = i & 31;             // partial layout [d][v]
             const float x = s / S;                         // values / v_length (models/transformer.py:38-39), applied to the sum
@@ -826,9 +836,10 @@ extern "C" int scream_kv_finalize_x3(const float* kv_partial, const int32_t* clo
     SCREAM_REQUIRE(kv_partial && cloud_row0 && cloud_len && kv_image, SCREAM_EINVAL);
     SCREAM_REQUIRE(n_kv >= 0 && cloud_begin >= 0 && row_base >= 0 && n_layers >= 1 && n_layers <= 65535, SCREAM_EINVAL);
     SCREAM_REQUIRE(n_layers == 1 || (partial_layer_stride > 0 && image_layer_stride > 0 && image_layer_stride % 16 == 0), SCREAM_EINVAL);
-    SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(kv_image) & 15) == 0, SCREAM_EINVAL);
+    SCREAM_REQUIRE(((reinterpret_cast<uintptr_t>(kv_image) | reinterpret_cast<uintptr_t>(kv_partial)) & 15) == 0 && partial_layer_stride % 4 == 0,
+                   SCREAM_EINVAL);
     if (n_kv == 0) return 0;
-    kv_finalize_x3_kernel<<<dim3(n_kv * SCREAM_NHEAD, n_layers), dim3(1024), 0, as_stream(stream)>>>(
+    kv_finalize_x3_kernel<<<dim3(n_kv * SCREAM_NHEAD, n_layers), dim3(KVF_THREADS), 0, as_stream(stream)>>>(
         kv_partial, cloud_row0, cloud_len, row_base, cloud_begin, reinterpret_cast<char*>(kv_image), partial_layer_stride, image_layer_stride);
     SCREAM_LAUNCH_CHECK();
     return 0;

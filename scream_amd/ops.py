@@ -228,12 +228,14 @@ def kv_finalize(part, cloud_row0, cloud_len, row_base: int, cloud_begin: int, n_
     return kv
 
 
-def pe_embed_ln(xyz, tile_cloud, center, dim_t, emb_w, emb_b, gamma, beta) -> torch.Tensor:
+def pe_embed_ln(xyz, tile_cloud, center, dim_t, emb_w, emb_b, gamma, beta, frag: bool = False) -> torch.Tensor:
+    """A1.  frag=True: the same values in the fragment-major layout (include/scream_hip.h SCREAM_ACT_FRAG; act_layout undoes it)."""
     rows = xyz.shape[0]
     feats = torch.empty(rows, D_MODEL, device=xyz.device, dtype=torch.float32)
-    check(_lib.load().scream_pe_embed_ln(_p(xyz), _p(tile_cloud, torch.int32), _p(center), _p(dim_t), _p(emb_w),
-                                         _p(emb_b), _p(gamma), _p(beta), _p(feats), rows, _stream()),
-          "scream_pe_embed_ln")
+    lib = _lib.load()
+    fn, name = (lib.scream_pe_embed_ln_frag, "scream_pe_embed_ln_frag") if frag else (lib.scream_pe_embed_ln, "scream_pe_embed_ln")
+    check(fn(_p(xyz), _p(tile_cloud, torch.int32), _p(center), _p(dim_t), _p(emb_w),
+             _p(emb_b), _p(gamma), _p(beta), _p(feats), rows, _stream()), name)
     return feats
 
 

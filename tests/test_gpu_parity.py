@@ -204,6 +204,11 @@ def test_pe_embed_prenorm_vs_oracle(golden):
     want_t = O.embed_prenorm(tgt, tgt, sd)
     torch.testing.assert_close(feats[:150], want_s, rtol=1e-4, atol=2e-5)
     torch.testing.assert_close(feats[b.rows_src: b.rows_src + 70], want_t, rtol=1e-4, atol=2e-5)
+    # the fused forward's variant writes the same values fragment-major, without the separate layout pass
+    frag = ops.pe_embed_ln(b.xyz, b.tile_cloud, b.center, dev(pe_dim_t()), dev(sd["embedding.weight"][:, :, 0].contiguous()),
+                           dev(sd["embedding.bias"]), dev(sd["pre_norm.weight"]), dev(sd["pre_norm.bias"]), frag=True)
+    assert torch.equal(ops.act_layout(frag, False).cpu(), feats)
+    assert torch.equal(frag.cpu(), ops.act_layout(dev(feats), True).cpu())
 
 
 # ---------------------------------------------------------------------- A3 linear attention
