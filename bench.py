@@ -60,7 +60,7 @@ GEMM_NAMES = {0: "gemm<EPI_NONE>", 1: "gemm<EPI_ELU1> (cross-layer q projection)
               7: "tail_kernel (attention apply, merge + LayerNorm1, FFN + LayerNorm2 in one launch; N = 256 + 2 x 1024 columns)",
               2: "gemm<EPI_RELU> (FFN 256->1024)", 3: "gemm<EPI_BIAS_RELU> (coor_mlp)",
               4: "gemm<EPI_RES_LN> (merge, FFN 1024->256 + residual + LayerNorm)",
-              100: "pe_embed_ln_kernel", 101: "kv_finalize_tiles_kernel", 102: "attn_apply_kernel",
+              100: "pe_embed_ln_kernel", 101: "kv_finalize_x3_kernel (kv_finalize_tiles_kernel when the layer tail is unfused)", 102: "attn_apply_kernel",
               103: "coor_head_kernel"}
 
 
