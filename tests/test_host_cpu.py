@@ -539,6 +539,45 @@ def test_empty_dataset_evaluates_to_zeros():
     assert ev.evaluate_loader(None, Empty(), verbose=False) == (0.0, 0.0, 0.0, 0.0)
 
 
+def test_evaluate_loader_keeps_in_flight_batches_enqueued_and_collects_in_order(monkeypatch):
+    """evaluate_loader(in_flight=n): n batches are enqueued before the oldest is collected, a slot (stream, staging set,
+    workspace) is reused only after the batch that last used it has been collected, rows come back in dataset order."""
+    from scream_amd import dist as sdist
+    from scream_amd import evaluate as ev
+    log = []
+
+    def fake_async(net, items, ids, corr, dis_thresh, icp, pred_hook=None, stream=None):
+        k = len([e for e in log if e[0] == "enq"])
+        log.append(("enq", k))
+
+        def fin():
+            log.append(("fin", k))
+            rows = np.zeros((len(ids), sdist.ROW_WIDTH))
+            rows[:, 0] = ids
+            rows[:, sdist.COL_RE] = ids
+            return rows
+        return fin
+    monkeypatch.setattr(ev, "evaluate_items_async", fake_async)
+
+    class DS:
+        def __len__(self):
+            return 22
+
+        def __getitem__(self, i):
+            z = torch.zeros(4, 3)
+            return (z, z, torch.eye(3), torch.zeros(3, 1), 1.0, torch.tensor([0, 2]), torch.eye(6), torch.zeros(3), 0)
+    for n in (2, 3, 4):
+        log.clear()
+        ev.evaluate_loader(None, DS(), batch_pairs=4, icp=None, verbose=False, in_flight=n)
+        n_batches = 6
+        assert [k for t, k in log if t == "fin"] == list(range(n_batches))  # collected oldest first
+        for k in range(n_batches):
+            if k >= n:  # slot k % n is reused by batch k only after batch k - n was collected
+                assert log.index(("fin", k - n)) < log.index(("enq", k))
+            if k >= n - 1 and k + 1 < n_batches:  # ... and not before n batches were enqueued
+                assert log.index(("enq", k)) < log.index(("fin", k - (n - 1)))
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus N` with no launcher around it spawns the N ranks itself (CPU-only parent), forwards rank
     0's single JSON line and propagates a failing rank's exit code (round-1 verdict: the driver's command form)."""
