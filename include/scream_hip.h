@@ -348,7 +348,7 @@ int scream_transformation_error(const float* T_pred, const float* T_gt, int32_t 
  * evaluate_3d_match.py:106-113 / evaluate_kitti.py:61-70 (open3d is absent here: parity with open3d is
  * unpinned; the loop is open3d's published RegistrationICP and is checked against oracle/icp_ref.py).
  * src/ref packed, normalised frame; metric points are x / s + c.  T [n_pairs,16] holds the initial
- * transforms on entry and the refined ones on return.  Per iteration: transform the source, thresholded
+ * transforms on entry and the refined ones on return.  Per iteration (one launch): transform the source, thresholded
  * 1-NN (distance <= max_corr_dist), fitness = #corr / N and inlier_rmse = sqrt(mean d^2); stop a pair when
  * both change by less than rel_fitness / rel_rmse or after max_iter updates; otherwise compose the Kabsch
  * update of the correspondences.  fitness_rmse [n_pairs,2] and iters [n_pairs] may be NULL. */

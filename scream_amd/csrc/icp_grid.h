@@ -22,16 +22,17 @@ __device__ __forceinline__ int cell_coord(float x, float o, float inv_h, int n) 
 
 // Nearest target of ONE query point within the radius (thresh = radius^2), over the nine x-runs of the 27 cells around it:
 // the same explicitly rounded distance as nn_search_kernel with s = 1, ties to the lowest ORIGINAL target index.
-// st / sp / si: the pair's cell starts, sorted records {b, |b|^2} and original indices.  Shared by grid_search_kernel
-// (one launch per iteration).
+// st / sp / si: the pair's cell starts, sorted records {b, |b|^2} and original indices; b_out: the coordinates of the winner
+// (the record's own, i.e. what ref[idx] holds).  Used by icp_iter_kernel (kabsch.hip), one launch per iteration.
 __device__ __forceinline__ void grid_search_point(const GridParam& g, const int32_t* __restrict__ st, const float* __restrict__ sp,
                                                   const int32_t* __restrict__ si, float ax, float ay, float az, float thresh,
-                                                  int32_t& idx_out, float& d_out, uint8_t& valid_out) {
+                                                  int32_t& idx_out, float& d_out, uint8_t& valid_out, float (&b_out)[3]) {
     const float sa = __fadd_rn(__fadd_rn(__fmul_rn(ax, ax), __fmul_rn(ay, ay)), __fmul_rn(az, az));
     const int cx = cell_coord(ax, g.ox, g.inv_h, g.nx), cy = cell_coord(ay, g.oy, g.inv_h, g.ny), cz = cell_coord(az, g.oz, g.inv_h, g.nz);
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
     float best = __builtin_inff();
     int bi = 0x7fffffff;
+    float bx = 0.f, by = 0.f, bz = 0.f;
     // The nine x-runs: all eighteen cell-start loads go out together (a thread's time here is memory latency: one dependent
     // round per run cost 32 us per search launch), then the candidates of each run, four at a time.
     int jb[9], je[9];
@@ -51,6 +52,9 @@ __device__ __forceinline__ void grid_search_point(const GridParam& g, const int3
         if (d < best || (d == best && o < bi)) {
             best = d;
             bi = o;
+            bx = b[0];
+            by = b[1];
+            bz = b[2];
         }
     };
 #pragma unroll
@@ -73,6 +77,9 @@ __device__ __forceinline__ void grid_search_point(const GridParam& g, const int3
     idx_out = ok ? bi : -1;
     d_out = ok ? best : __builtin_inff();
     valid_out = ok ? 1 : 0;
+    b_out[0] = bx;
+    b_out[1] = by;
+    b_out[2] = bz;
 }
 #endif
 
@@ -86,10 +93,6 @@ struct IcpGrid {
 int64_t icp_grid_workspace_floats(int64_t ref_rows_total, int32_t n_pairs);
 int icp_grid_build(const float* ref_m, const float* ref_prep, const int32_t* r_row0, const int32_t* r_len, int32_t n_pairs,
                    int32_t max_r_len, int64_t ref_rows_total, float radius, float* work, IcpGrid* out, hipStream_t st);
-// q = T[pair] . src (written out for the Kabsch update's gather), then the thresholded nearest target of q on the grid
-int icp_grid_search(const IcpGrid& g, const float* src, const float* T, float* q, const int32_t* q_row0, const int32_t* q_len,
-                    const int32_t* r_row0, int32_t n_pairs, int32_t max_q_len, float thresh, int32_t* idx, float* dmin,
-                    uint8_t* valid, hipStream_t st);
 // nn_search.hip: ref_prep[row] = {b / s, |b / s|^2} (the brute-force search's own preparation) and the padding fill
 int nn_prepare_targets(const float* ref, const int32_t* r_row0, const int32_t* r_len, const float* s, int32_t n_pairs,
                        int32_t max_r_len, float* ref_prep, hipStream_t st);

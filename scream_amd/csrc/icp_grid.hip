@@ -12,7 +12,8 @@
 // below the threshold lies in the 27 cells (the 1 % margin on h is four orders of magnitude above the rounding of the
 // cell arithmetic and of the distance).  Where no target is inside the radius the brute-force search still returns the
 // global nearest neighbour with valid = 0; this one returns idx = -1, dmin = inf, valid = 0 -- the ICP update reads
-// neither for such a point (icp_update_kernel, kabsch_block: valid only).
+// neither for such a point (icp_store_partial, kabsch.hip: valid correspondences only).
+// The search itself (grid_search_point, icp_grid.h) is called from icp_iter_kernel (kabsch.hip), which does a whole iteration.
 //
 // Build, once per scream_icp_p2p call: bounding box per pair -> grid parameters (the cell edge grows by 2^(1/3) until the
 // grid fits ICP_GRID_CELLS cells: correct for any h >= the radius, only more candidates) -> count -> exclusive scan ->
@@ -135,36 +136,6 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float* __restri
     sorted_idx[r0 + pos] = i;
 }
 
-// grid (ceil(max_q_len / 256), n_pairs): one query per thread -- the source point under the pair's current transform (the
-// arithmetic of icp_transform_kernel, kabsch.hip; written to q for the Kabsch update) -- same rounding sequence as
-// nn_search_kernel with s = 1
-__global__ __launch_bounds__(256) void grid_search_kernel(const float* __restrict__ src, const float* __restrict__ T,
-                                                         float* __restrict__ query, const int32_t* __restrict__ q_row0,
-                                                         const int32_t* __restrict__ q_len, const int32_t* __restrict__ r_row0,
-                                                         const GridParam* __restrict__ gp, const int32_t* __restrict__ start,
-                                                         const float* __restrict__ sorted_prep,
-                                                         const int32_t* __restrict__ sorted_idx, float thresh,
-                                                         int32_t* __restrict__ idx, float* __restrict__ dmin,
-                                                         uint8_t* __restrict__ valid) {
-    const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= q_len[p]) return;
-    const int64_t row = (int64_t)q_row0[p] + i;
-    const float* t = T + p * 16;
-    const float x = src[row * 3 + 0], y = src[row * 3 + 1], z = src[row * 3 + 2];
-    const float ax = t[0] * x + t[1] * y + t[2] * z + t[3], ay = t[4] * x + t[5] * y + t[6] * z + t[7], az = t[8] * x + t[9] * y + t[10] * z + t[11];
-    query[row * 3 + 0] = ax;
-    query[row * 3 + 1] = ay;
-    query[row * 3 + 2] = az;
-    int32_t bi;
-    float best;
-    uint8_t ok;
-    scream_internal::grid_search_point(gp[p], start + (int64_t)p * (ICP_GRID_CELLS + 1), sorted_prep + (int64_t)r_row0[p] * 4,
-                                       sorted_idx + r_row0[p], ax, ay, az, thresh, bi, best, ok);
-    idx[row] = bi;
-    dmin[row] = best;
-    valid[row] = ok;
-}
-
 }  // namespace
 
 namespace scream_internal {
@@ -201,17 +172,6 @@ int icp_grid_build(const float* ref_m, const float* ref_prep, const int32_t* r_r
         grid_scatter_kernel<<<grid, dim3(256), 0, st>>>(ref_prep, r_row0, r_len, cell_of, cursor, sorted_prep, sorted_idx);
         SCREAM_LAUNCH_CHECK();
     }
-    return 0;
-}
-
-int icp_grid_search(const IcpGrid& g, const float* src, const float* T, float* q, const int32_t* q_row0, const int32_t* q_len,
-                    const int32_t* r_row0, int32_t n_pairs, int32_t max_q_len, float thresh, int32_t* idx, float* dmin,
-                    uint8_t* valid, hipStream_t st) {
-    if (max_q_len <= 0 || n_pairs <= 0) return 0;
-    grid_search_kernel<<<dim3((max_q_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(
-        src, T, q, q_row0, q_len, r_row0, reinterpret_cast<const GridParam*>(g.params), g.start, g.sorted_prep, g.sorted_idx, thresh, idx,
-        dmin, valid);
-    SCREAM_LAUNCH_CHECK();
     return 0;
 }
 

@@ -370,145 +370,226 @@ __global__ __launch_bounds__(256) void fill_f32_kernel(float* __restrict__ p, fl
     if (i < n) p[i] = v;
 }
 
-struct IcpState {  // per pair
+// ---- the ICP iteration (round 3, second version): ONE launch per iteration --------------------------------------------------
+// A search launch leaves, per 256-point chunk of a pair, a PARTIAL of its correspondences: count, sum d^2, sum a, sum b, sum a b^T
+// (17 doubles; a = the transformed source point, b = its target).  The next launch starts, in EVERY block of the pair, by summing
+// the pair's partials in a fixed order and deriving from them what rounds 1-3's separate update launch derived from a second
+// gathering pass: fitness / inlier RMSE, the convergence test, and the Kabsch update composed into T -- then searches under the
+// new T.  One dependent launch per iteration instead of two (rounds 1-2: three), no gather of idx -> target rows at all.
+// The covariance about the fp32 centroids cA, cB (utils.py:155-166) is expanded from the one-pass sums in fp64:
+//   sum (a - cA)(b - cB)^T = sum a b^T - cA (sum b)^T - (sum a) cB^T + n cA cB^T
+// (the two-pass form rounds the differences to fp32 first: 1e-7 relative apart, both far inside the 1e-4 of the ICP tests; the
+// A9 solve of the parity path, kabsch_block above, is untouched).  Buffers indexed by the parity of the launch are written by the
+// pair's block 0 and read by every block of the NEXT launch, so no block ever reads what another block of its own launch writes.
+struct IcpState {  // per pair: fitness and inlier RMSE of the last evaluated search
     float fitness, rmse;
-    int32_t done, iters;
 };
 
-constexpr int ICP_NT = 512;   // threads of an ICP update workgroup (one workgroup per pair)
-constexpr int ICP_KC = 16;    // correspondences a thread keeps in registers between the passes (pairs up to 8 192 points)
+constexpr int ICP_NP = 17;  // doubles per chunk partial
+constexpr int ICP_NG = 15;  // strided groups the partials of a pair are summed in (15 x 17 = 255 threads)
 
-// One workgroup (ICP_NT threads) per pair: fitness / inlier RMSE of the current correspondences, convergence test, and (if
-// the pair goes on) the Kabsch update composed into T.  q = transformed source, idx/valid/dmin from the search.  Returns
-// (block-uniform) whether the pair has stopped.  Round 3: ONE gathering pass -- a thread's correspondences (a = q_i, b = its
-// target, the distance) stay in registers for the centroid-relative covariance pass, where rounds 1-2 walked the dependent
-// chain valid -> idx -> target row three times with 256 threads (43 us per launch, more than the search before it).  Same
-// formulas as kabsch_block (centroids sum / (K + 1e-6) in fp32, covariance of the fp32 differences summed in fp64); the
-// summation order is fixed by ICP_NT, so the grid and the brute-force search paths, which share this kernel, stay bit-identical.
-__device__ bool icp_update_block(int p, const float* q, const float* __restrict__ ref,
-                                 const int32_t* __restrict__ src_row0, const int32_t* __restrict__ src_len,
-                                 const int32_t* __restrict__ ref_row0, const int32_t* idx,
-                                 const uint8_t* valid, const float* dmin, int iter, int max_iter,
-                                 float rel_fitness, float rel_rmse, float* T, IcpState* state,
-                                 int32_t* act_len, float* fit_rmse_out, int32_t* iters_out) {
-    __shared__ double red[ICP_NT / 64 * 9];
+struct IcpArgs {
+    const int32_t* src_row0;
+    const int32_t* src_len;
+    float* Tbuf;         // [2][n_pairs][16]: T of search it lives at parity it & 1
+    IcpState* state;     // [2][n_pairs]: evaluation of search e at parity e & 1
+    double* part;        // [2][n_chunks_total][ICP_NP]: partials of search it at parity it & 1; chunk c of pair p = src_row0[p] / 256 + p + c
+    int32_t* done;       // [n_pairs] 0 -> 1, once
+    int32_t* act_len;    // [n_pairs] src_len, 0 once done (the brute-force yardstick's kernels take their work from it)
+    int64_t part_stride; // n_chunks_total * ICP_NP
+    int32_t n_pairs, max_iter;
+    float rel_fitness, rel_rmse;
+    float* T_out;        // [n_pairs][16] the caller's transforms
+    float* fit_rmse_out; // may be NULL
+    int32_t* iters_out;  // may be NULL
+};
+
+__device__ __forceinline__ int icp_chunks(int n) { return n > 0 ? (n + 255) / 256 : 1; }  // (an empty source still has its block 0)
+__device__ __forceinline__ int64_t icp_chunk0(const IcpArgs& a, int p) { return (int64_t)a.src_row0[p] / 256 + p; }
+
+// Whole block (256 threads).  Evaluates search e = it - 1 of pair p from its partials; returns (block-uniform) whether the pair
+// stops.  If it goes on, T_sh (LDS) holds T_it = dT . T_e.  `writer`: this block publishes state / done / outputs / T_it.
+__device__ bool icp_pose_step(const IcpArgs& a, int p, int it, bool writer, float* T_sh) {
+    __shared__ double grp[ICP_NG][ICP_NP];
+    __shared__ double tot[ICP_NP];
     __shared__ float dT_sh[16];
-    const IcpState st = state[p];
-    const int n = src_len[p];
-    const int64_t r0 = src_row0[p], rr0 = ref_row0[p];
-    float ca[ICP_KC][3], cb[ICP_KC][3];
-    bool ok[ICP_KC];
-    auto fetch = [&](int i, float (&a)[3], float (&b)[3], float& d) {
-        const int64_t row = r0 + i;
-        if (!valid[row]) return false;
-        const int64_t rrow = rr0 + idx[row];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            a[k] = q[row * 3 + k];
-            b[k] = ref[rrow * 3 + k];
-        }
-        d = dmin[row];
-        return true;
-    };
-    double acc[8];  // count, sum d, sum a, sum b
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.0;
-    auto add1 = [&](const float (&a)[3], const float (&b)[3], float d) {
-        acc[0] += 1.0;
-        acc[1] += (double)d;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            acc[2 + k] += (double)a[k];
-            acc[5 + k] += (double)b[k];
-        }
-    };
-#pragma unroll
-    for (int c = 0; c < ICP_KC; ++c) {
-        const int i = threadIdx.x + c * ICP_NT;
-        float d = 0.f;
-        ok[c] = i < n && fetch(i, ca[c], cb[c], d);
-        if (ok[c]) add1(ca[c], cb[c], d);
-    }
-    for (int i = threadIdx.x + ICP_KC * ICP_NT; i < n; i += ICP_NT) {  // (clouds beyond 8 192 points: the rest is re-fetched below)
-        float a[3], b[3], d;
-        if (fetch(i, a, b, d)) add1(a, b, d);
-    }
-    block_sum<8, ICP_NT>(acc, red);
-    const float fitness = n > 0 ? (float)(acc[0] / n) : 0.f;
-    const float rmse = acc[0] > 0 ? (float)sqrt(acc[1] / acc[0]) : 0.f;
-    const bool converged = iter > 0 && fabsf(st.fitness - fitness) < rel_fitness && fabsf(st.rmse - rmse) < rel_rmse;
-    const bool stop = converged || iter >= max_iter;
-    __syncthreads();  // everyone has read state[p] before thread 0 rewrites it
-    if (threadIdx.x == 0) {
-        IcpState o = {fitness, rmse, stop ? 1 : 0, iter};
-        state[p] = o;
-        if (fit_rmse_out) {
-            fit_rmse_out[2 * p + 0] = fitness;
-            fit_rmse_out[2 * p + 1] = rmse;
-        }
-        if (iters_out) iters_out[p] = iter;  // number of updates applied
-        if (stop) act_len[p] = 0;            // a finished pair costs no further transform / search work
-    }
-    if (stop) return true;
-    const float denom = (float)acc[0] + 1e-6f;  // utils.py:155-158 with unit weights
-    const float cA[3] = {(float)acc[2] / denom, (float)acc[3] / denom, (float)acc[4] / denom};
-    const float cB[3] = {(float)acc[5] / denom, (float)acc[6] / denom, (float)acc[7] / denom};
-    double h[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) h[k] = 0.0;
-    auto add2 = [&](const float (&a)[3], const float (&b)[3]) {
-        const float am[3] = {a[0] - cA[0], a[1] - cA[1], a[2] - cA[2]};
-        const float bm[3] = {b[0] - cB[0], b[1] - cB[1], b[2] - cB[2]};
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) h[r * 3 + c] += (double)am[r] * (double)bm[c];
-    };
-#pragma unroll
-    for (int c = 0; c < ICP_KC; ++c)
-        if (ok[c]) add2(ca[c], cb[c]);
-    for (int i = threadIdx.x + ICP_KC * ICP_NT; i < n; i += ICP_NT) {
-        float a[3], b[3], d;
-        if (fetch(i, a, b, d)) add2(a, b);
-    }
-    block_sum<9, ICP_NT>(h, red);
-    if (threadIdx.x < 64) {  // wave 0, every lane redundantly (wave-uniform data)
-        double H[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) H[r][c] = (double)(float)h[r * 3 + c];
-        float dT[16];
-        solve_pose(H, cA, cB, dT);
-        if (threadIdx.x < 16) dT_sh[threadIdx.x] = dT[threadIdx.x];
+    __shared__ int stop_sh;
+    const int e = it - 1, n = a.src_len[p], nb = icp_chunks(n);
+    const double* part = a.part + (int64_t)(e & 1) * a.part_stride + icp_chunk0(a, p) * ICP_NP;
+    const float* T_e = a.Tbuf + ((int64_t)(e & 1) * a.n_pairs + p) * 16;
+    const int tid = threadIdx.x;
+    if (tid < ICP_NG * ICP_NP) {
+        const int k = tid % ICP_NP, g = tid / ICP_NP;
+        double sum = 0.0;
+        for (int c = g; c < nb; c += ICP_NG) sum += part[(int64_t)c * ICP_NP + k];
+        grp[g][k] = sum;
     }
     __syncthreads();
-    float v = 0.f;
-    if (threadIdx.x < 16) {  // T <- dT . T
-        const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
+    if (tid < ICP_NP) {
+        double sum = grp[0][tid];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v += dT_sh[i * 4 + k] * T[p * 16 + k * 4 + j];
+        for (int g = 1; g < ICP_NG; ++g) sum += grp[g][tid];
+        tot[tid] = sum;
     }
     __syncthreads();
-    if (threadIdx.x < 16) T[p * 16 + threadIdx.x] = v;
-    return false;
+    if (tid < 64) {  // wave 0, every lane redundantly (wave-uniform data)
+        const double cnt = tot[0];
+        const float fitness = n > 0 ? (float)(cnt / n) : 0.f;
+        const float rmse = cnt > 0 ? (float)sqrt(tot[1] / cnt) : 0.f;
+        const IcpState prev = a.state[(int64_t)((e + 1) & 1) * a.n_pairs + p];  // evaluation e - 1 (unused at e == 0)
+        const bool converged = e > 0 && fabsf(prev.fitness - fitness) < a.rel_fitness && fabsf(prev.rmse - rmse) < a.rel_rmse;
+        const bool stop = converged || e >= a.max_iter;
+        if (tid == 0) {
+            stop_sh = stop ? 1 : 0;
+            if (writer) {
+                const IcpState o = {fitness, rmse};
+                a.state[(int64_t)(e & 1) * a.n_pairs + p] = o;
+                if (a.fit_rmse_out) {
+                    a.fit_rmse_out[2 * p + 0] = fitness;
+                    a.fit_rmse_out[2 * p + 1] = rmse;
+                }
+                if (a.iters_out) a.iters_out[p] = e;  // number of updates applied
+                if (stop) {
+                    a.done[p] = 1;
+                    a.act_len[p] = 0;
+                }
+            }
+        }
+        if (stop) {
+            if (writer && tid < 16) a.T_out[p * 16 + tid] = T_e[tid];
+        } else {
+            const float denom = (float)cnt + 1e-6f;  // utils.py:155-158 with unit weights
+            const float cA[3] = {(float)tot[2] / denom, (float)tot[3] / denom, (float)tot[4] / denom};
+            const float cB[3] = {(float)tot[5] / denom, (float)tot[6] / denom, (float)tot[7] / denom};
+            double H[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double h = tot[8 + r * 3 + c] - (double)cA[r] * tot[5 + c] - tot[2 + r] * (double)cB[c] + cnt * (double)cA[r] * (double)cB[c];
+                    H[r][c] = (double)(float)h;  // the reference holds H in fp32
+                }
+            float dT[16];
+            solve_pose(H, cA, cB, dT);
+            if (tid < 16) dT_sh[tid] = dT[tid];
+        }
+    }
+    __syncthreads();
+    const bool stop = stop_sh != 0;
+    if (!stop) {
+        if (tid < 16) {  // T_it = dT . T_e
+            const int i = tid >> 2, j = tid & 3;
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v += dT_sh[i * 4 + k] * T_e[k * 4 + j];
+            T_sh[tid] = v;
+            if (writer) a.Tbuf[((int64_t)(it & 1) * a.n_pairs + p) * 16 + tid] = v;
+        }
+        __syncthreads();
+    }
+    return stop;
 }
 
-__global__ __launch_bounds__(ICP_NT) void icp_update_kernel(const float* __restrict__ q, const float* __restrict__ ref,
-                                                           const int32_t* __restrict__ src_row0,
-                                                           const int32_t* __restrict__ src_len,
-                                                           const int32_t* __restrict__ ref_row0,
-                                                           const int32_t* __restrict__ idx,
-                                                           const uint8_t* __restrict__ valid,
-                                                           const float* __restrict__ dmin, int iter, int max_iter,
-                                                           float rel_fitness, float rel_rmse, float* __restrict__ T,
-                                                           IcpState* __restrict__ state, int32_t* __restrict__ act_len,
-                                                           float* __restrict__ fit_rmse_out,
-                                                           int32_t* __restrict__ iters_out) {
+// the block's partial of search `it`: one correspondence (or none) per thread, summed over the 256 threads in a fixed order
+__device__ void icp_store_partial(const IcpArgs& a, int p, int c, int it, bool ok, float ax, float ay, float az, const float (&b)[3],
+                                  float d) {
+    __shared__ double red[4 * ICP_NP];
+    double v[ICP_NP];
+#pragma unroll
+    for (int k = 0; k < ICP_NP; ++k) v[k] = 0.0;
+    if (ok) {
+        const float av[3] = {ax, ay, az};
+        v[0] = 1.0;
+        v[1] = (double)d;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            v[2 + k] = (double)av[k];
+            v[5 + k] = (double)b[k];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) v[8 + r * 3 + cc] = (double)av[r] * (double)b[cc];
+    }
+    block_sum<ICP_NP, 256>(v, red);
+    if (threadIdx.x < ICP_NP) {
+        double out = v[0];
+#pragma unroll
+        for (int k = 1; k < ICP_NP; ++k)
+            if ((int)threadIdx.x == k) out = v[k];
+        a.part[(int64_t)(it & 1) * a.part_stride + (icp_chunk0(a, p) + c) * ICP_NP + threadIdx.x] = out;
+    }
+}
+
+// grid (ceil(max_src_len / 256), n_pairs): [evaluate search it - 1, update T] + search it on the target grid + partial
+__global__ __launch_bounds__(256) void icp_iter_kernel(IcpArgs a, const float* __restrict__ src_m, const int32_t* __restrict__ r_row0,
+                                                      const scream_internal::GridParam* __restrict__ gp,
+                                                      const int32_t* __restrict__ start, const float* __restrict__ sorted_prep,
+                                                      const int32_t* __restrict__ sorted_idx, float thresh, int it) {
+    __shared__ float T_sh[16];
+    const int p = blockIdx.y, c = blockIdx.x;
+    // (block 0 of this very launch may be setting the flag: a block that sees it early returns where it would have returned
+    // after deriving the same stop -- the derivation is deterministic)
+    if (a.done[p]) return;
+    const int n = a.src_len[p];
+    if (c >= icp_chunks(n)) return;
+    if (it > 0) {
+        if (icp_pose_step(a, p, it, c == 0, T_sh)) return;
+    } else {
+        if (threadIdx.x < 16) T_sh[threadIdx.x] = a.Tbuf[(int64_t)p * 16 + threadIdx.x];
+        __syncthreads();
+    }
+    const int i = c * 256 + threadIdx.x;
+    const bool in = i < n;
+    float ax = 0.f, ay = 0.f, az = 0.f, d = 0.f, b[3] = {0.f, 0.f, 0.f};
+    uint8_t ok = 0;
+    if (in) {
+        const int64_t row = (int64_t)a.src_row0[p] + i;
+        const float x = src_m[row * 3 + 0], y = src_m[row * 3 + 1], z = src_m[row * 3 + 2];
+        const float* t = T_sh;  // (the arithmetic of icp_transform_kernel)
+        ax = t[0] * x + t[1] * y + t[2] * z + t[3];
+        ay = t[4] * x + t[5] * y + t[6] * z + t[7];
+        az = t[8] * x + t[9] * y + t[10] * z + t[11];
+        int32_t bi;
+        scream_internal::grid_search_point(gp[p], start + (int64_t)p * (ICP_GRID_CELLS + 1), sorted_prep + (int64_t)r_row0[p] * 4,
+                                           sorted_idx + r_row0[p], ax, ay, az, thresh, bi, d, ok, b);
+    }
+    icp_store_partial(a, p, c, it, ok != 0, ax, ay, az, b, d);
+}
+
+// one block per pair: the evaluation (+ update) alone -- the last search's, and every iteration's on the brute-force yardstick
+__global__ __launch_bounds__(256) void icp_pose_kernel(IcpArgs a, int it) {
+    __shared__ float T_sh[16];
     const int p = blockIdx.x;
-    if (state[p].done) return;  // block-uniform
-    icp_update_block(p, q, ref, src_row0, src_len, ref_row0, idx, valid, dmin, iter, max_iter, rel_fitness, rel_rmse, T, state,
-                     act_len, fit_rmse_out, iters_out);
+    if (a.done[p]) return;
+    icp_pose_step(a, p, it, true, T_sh);
+}
+
+// SCREAM_ICP_BRUTE=1: the partials of a search done by icp_transform_kernel + scream_nn_search (same per-thread values, same sums)
+__global__ __launch_bounds__(256) void icp_partials_kernel(IcpArgs a, const float* __restrict__ q, const float* __restrict__ ref,
+                                                          const int32_t* __restrict__ ref_row0, const int32_t* __restrict__ idx,
+                                                          const uint8_t* __restrict__ valid, const float* __restrict__ dmin, int it) {
+    const int p = blockIdx.y, c = blockIdx.x;
+    if (a.done[p]) return;
+    const int n = a.src_len[p];
+    if (c >= icp_chunks(n)) return;
+    const int i = c * 256 + threadIdx.x;
+    float ax = 0.f, ay = 0.f, az = 0.f, d = 0.f, b[3] = {0.f, 0.f, 0.f};
+    bool ok = false;
+    if (i < n) {
+        const int64_t row = (int64_t)a.src_row0[p] + i;
+        ok = valid[row] != 0;
+        if (ok) {
+            const int64_t rrow = (int64_t)ref_row0[p] + idx[row];
+            ax = q[row * 3 + 0];
+            ay = q[row * 3 + 1];
+            az = q[row * 3 + 2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) b[k] = ref[rrow * 3 + k];
+            d = dmin[row];
+        }
+    }
+    icp_store_partial(a, p, c, it, ok, ax, ay, az, b, d);
 }
 
 }  // namespace
@@ -544,12 +625,17 @@ extern "C" int scream_transformation_error(const float* T_pred, const float* T_g
     return 0;
 }
 
+namespace {
+int64_t icp_chunks_total(int64_t src_rows_total, int32_t n_pairs) { return src_rows_total / 256 + n_pairs + 1; }
+}  // namespace
+
 extern "C" int64_t scream_icp_workspace_bytes(int64_t src_rows_total, int64_t ref_rows_total, int32_t n_pairs) {
     if (src_rows_total < 0 || ref_rows_total < 0 || n_pairs < 0) return SCREAM_EINVAL;
-    // src metric + transformed src (3 floats each), ref metric (3) + nn ref_prep (4), keys (2), idx, dmin, valid, ones, state
-    // + the target grid of icp_grid.hip
-    return (src_rows_total * (3 + 3 + 2 + 1 + 1 + 1) + ref_rows_total * (3 + 4) + (int64_t)n_pairs * 16 +
-            scream_internal::icp_grid_workspace_floats(ref_rows_total, n_pairs)) * 4 + 8192;
+    // src metric + transformed src (3 floats each), ref metric (3) + nn ref_prep (4), keys (2), idx, dmin, valid, per pair: ones,
+    // T x 2 (32), state x 2 (4), done, act_len; the chunk partials (2 parities x 17 doubles) + the target grid of icp_grid.hip
+    return (src_rows_total * (3 + 3 + 2 + 1 + 1 + 1) + ref_rows_total * (3 + 4) + (int64_t)n_pairs * (1 + 32 + 4 + 1 + 1) +
+            icp_chunks_total(src_rows_total, n_pairs) * (2 * ICP_NP * 2) +
+            scream_internal::icp_grid_workspace_floats(ref_rows_total, n_pairs)) * 4 + 16384;
 }
 
 extern "C" int scream_icp_p2p(const float* src, const float* ref, const int32_t* src_row0, const int32_t* src_len,
@@ -574,17 +660,35 @@ extern "C" int scream_icp_p2p(const float* src, const float* ref, const int32_t*
     float* dmin = take(src_rows_total);
     uint8_t* valid = reinterpret_cast<uint8_t*>(take((src_rows_total + 3) / 4));
     float* ones = take(n_pairs);
-    IcpState* state = reinterpret_cast<IcpState*>(take((int64_t)n_pairs * 4));
-    int32_t* act_len = reinterpret_cast<int32_t*>(take(n_pairs));
+    IcpArgs a{};
+    a.src_row0 = src_row0;
+    a.src_len = src_len;
+    a.Tbuf = take((int64_t)n_pairs * 32);
+    a.state = reinterpret_cast<IcpState*>(take((int64_t)n_pairs * 4));
+    a.done = reinterpret_cast<int32_t*>(take(n_pairs));
+    a.act_len = reinterpret_cast<int32_t*>(take(n_pairs));
+    a.part_stride = icp_chunks_total(src_rows_total, n_pairs) * ICP_NP;
+    a.part = reinterpret_cast<double*>(take(a.part_stride * 2 * 2));
+    a.n_pairs = n_pairs;
+    a.max_iter = max_iter;
+    a.rel_fitness = rel_fitness;
+    a.rel_rmse = rel_rmse;
+    a.T_out = T;
+    a.fit_rmse_out = fitness_rmse;
+    a.iters_out = iters;
     float* grid_work = take(scream_internal::icp_grid_workspace_floats(ref_rows_total, n_pairs));
     SCREAM_REQUIRE(reinterpret_cast<char*>(w) <= reinterpret_cast<char*>(workspace) + workspace_bytes, SCREAM_EINVAL);
     // SCREAM_ICP_BRUTE=1 (tests): every iteration on the brute-force search of nn_search.hip instead of the target grid
     const char* brute_env = getenv("SCREAM_ICP_BRUTE");
     const bool brute = brute_env && brute_env[0] == '1';
 
-    hipError_t e = hipMemsetAsync(state, 0, sizeof(IcpState) * n_pairs, st);
+    hipError_t e = hipMemsetAsync(a.done, 0, sizeof(int32_t) * n_pairs, st);
     if (e != hipSuccess) return (int)e;
-    e = hipMemcpyAsync(act_len, src_len, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToDevice, st);
+    e = hipMemsetAsync(a.state, 0, sizeof(IcpState) * 2 * n_pairs, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(a.act_len, src_len, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(a.Tbuf, T, sizeof(float) * 16 * n_pairs, hipMemcpyDeviceToDevice, st);  // T_0: parity 0
     if (e != hipSuccess) return (int)e;
     // ones[p] = 1.0f: the search's "scale" (it divides by it), since these clouds are already metric
     fill_f32_kernel<<<dim3((n_pairs + 255) / 256), dim3(256), 0, st>>>(ones, 1.0f, n_pairs);
@@ -600,41 +704,42 @@ extern "C" int scream_icp_p2p(const float* src, const float* ref, const int32_t*
         rc = scream_internal::icp_grid_build(ref_m, ref_prep, ref_row0, ref_len, n_pairs, max_ref_len, ref_rows_total, max_corr_dist,
                                              grid_work, &grid, st);
         if (rc != 0) return rc;
-        rc = scream_internal::nn_fill_padding(idx, dmin, valid, src_rows_total, st);
-        if (rc != 0) return rc;
     }
-    std::vector<IcpState> host_state;
+    const dim3 chunks((max_src_len > 0 ? max_src_len + 255 : 256) / 256, n_pairs);
+    std::vector<int32_t> host_done;
+    // launch `it` = [evaluate search it - 1, stop or update T] + search it; search max_iter is evaluated by a last pose launch
     for (int it = 0; it <= max_iter; ++it) {
-        int rc;
-        if (brute) {  // SCREAM_ICP_BRUTE=1, the yardstick of the tests: transform, then the brute-force search of nn_search.hip
+        if (brute) {  // SCREAM_ICP_BRUTE=1, the yardstick of the tests: the same steps as separate launches around scream_nn_search
+            if (it > 0) icp_pose_kernel<<<dim3(n_pairs), dim3(256), 0, st>>>(a, it);
             if (max_src_len > 0)
-                icp_transform_kernel<<<dim3((max_src_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(src_m, src_row0, act_len, T, q);
+                icp_transform_kernel<<<dim3((max_src_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(
+                    src_m, src_row0, a.act_len, a.Tbuf + (int64_t)(it & 1) * n_pairs * 16, q);
             SCREAM_LAUNCH_CHECK();
-            rc = scream_nn_search(q, ref_m, src_row0, act_len, ref_row0, ref_len, ones, n_pairs, max_src_len, max_ref_len,
-                                  src_rows_total, ref_rows_total, max_corr_dist * max_corr_dist, ref_prep, keys, idx, dmin, valid, stream);
-        } else {      // two launches per iteration: the transform rides in the grid search (same arithmetic, one launch fewer)
-            rc = scream_internal::icp_grid_search(grid, src_m, T, q, src_row0, act_len, ref_row0, n_pairs, max_src_len,
-                                                  max_corr_dist * max_corr_dist, idx, dmin, valid, st);
+            const int rc = scream_nn_search(q, ref_m, src_row0, a.act_len, ref_row0, ref_len, ones, n_pairs, max_src_len, max_ref_len,
+                                            src_rows_total, ref_rows_total, max_corr_dist * max_corr_dist, ref_prep, keys, idx, dmin, valid, stream);
+            if (rc != 0) return rc;
+            icp_partials_kernel<<<chunks, dim3(256), 0, st>>>(a, q, ref_m, ref_row0, idx, valid, dmin, it);
+        } else {
+            icp_iter_kernel<<<chunks, dim3(256), 0, st>>>(a, src_m, ref_row0, reinterpret_cast<const scream_internal::GridParam*>(grid.params),
+                                                          grid.start, grid.sorted_prep, grid.sorted_idx, max_corr_dist * max_corr_dist, it);
         }
-        if (rc != 0) return rc;
-        icp_update_kernel<<<dim3(n_pairs), dim3(ICP_NT), 0, st>>>(q, ref_m, src_row0, src_len, ref_row0, idx, valid, dmin, it,
-                                                               max_iter, rel_fitness, rel_rmse, T, state, act_len,
-                                                               fitness_rmse, iters);
         SCREAM_LAUNCH_CHECK();
         // Long schedules (KITTI asks for up to 1000 iterations, evaluate_kitti.py:69) usually converge in tens:
         // look at the flags every 32 iterations and stop launching once every pair is done.  Short schedules (the
         // 30-iteration default) never synchronise: converged pairs have frozen on the device and cost no search work,
-        // and a host that does not block here can keep the other lane and the next batch queued.
+        // and a host that does not block here can keep the other batches queued.
         if (max_iter > 64 && (it & 31) == 31 && it < max_iter) {
-            host_state.resize(n_pairs);
-            e = hipMemcpyAsync(host_state.data(), state, sizeof(IcpState) * n_pairs, hipMemcpyDeviceToHost, st);
+            host_done.resize(n_pairs);
+            e = hipMemcpyAsync(host_done.data(), a.done, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, st);
             if (e != hipSuccess) return (int)e;
             e = hipStreamSynchronize(st);
             if (e != hipSuccess) return (int)e;
             bool all_done = true;
-            for (const IcpState& hs : host_state) all_done = all_done && hs.done;
-            if (all_done) break;
+            for (int32_t d : host_done) all_done = all_done && d;
+            if (all_done) return 0;
         }
     }
+    icp_pose_kernel<<<dim3(n_pairs), dim3(256), 0, st>>>(a, max_iter + 1);
+    SCREAM_LAUNCH_CHECK();
     return 0;
 }
