@@ -153,11 +153,16 @@ int scream_gemm_qkv_split_f32(const float* A, int64_t lda, const void* W_packed,
  * M % 128 == 0, every pointer 16-byte aligned. */
 typedef struct {
     int32_t e_att, e_wm, e_m1, e_w1, e_h, e_w2;
+    int32_t e_y, e_wq; /* only with a next-layer query projection in the image (below): of the block output y and of that Wq */
 } scream_tail_exps_t;
-int64_t scream_tail_image_bytes(int32_t split);
+int64_t scream_tail_image_bytes(int32_t split, int32_t with_next_q);
 int64_t scream_kv_image_bytes(void);
-int scream_pack_tail(const float* Wm, const float* W1, const float* W2, int32_t split, const scream_tail_exps_t* exps,
-                     void* tail_image, void* stream);
+/* Wq_next (may be NULL; fp16 splits): q_proj.weight [256,256] of the NEXT layer when that layer takes its queries from this
+ * block's output rows (a cross layer behind a self layer, models/transformer.py:130): eight more stages in the image, and
+ * scream_layer_tail_f32 called with q_next != NULL ends every tile with Q'_next = elu(y . Wq_next^T) + 1 (fragment-major) --
+ * the separate scream_gemm_split_f32(..., SCREAM_EPI_ELU1) launch of that layer is then not needed. */
+int scream_pack_tail(const float* Wm, const float* W1, const float* W2, const float* Wq_next, int32_t split,
+                     const scream_tail_exps_t* exps, void* tail_image, void* stream);
 /* n_layers > 1: the partials of a batched key/value projection (scream_gemm_qkv_split_f32 with N = 512 n_layers): layer l
  * reads kv_partial + l * partial_layer_stride floats ((M/128) * 8 * 1056 of that GEMM) and writes its n_kv cloud images at
  * kv_image + l * image_layer_stride bytes.  n_layers == 1: strides ignored. */
@@ -167,8 +172,8 @@ int scream_kv_finalize_x3(const float* kv_partial, const int32_t* cloud_row0, co
 int scream_layer_tail_f32(const float* Q, const void* kv_image, const int32_t* tile_cloud,
                           int32_t kv_cloud_offset, const int32_t* cloud_len, const float* x,
                           const void* tail_image, const float* g1, const float* b1, const float* g2,
-                          const float* b2, float* y, int64_t M, int32_t split, const scream_tail_exps_t* exps,
-                          void* stream);
+                          const float* b2, float* y, float* q_next, int64_t M, int32_t split,
+                          const scream_tail_exps_t* exps, void* stream);
 
 /* ---- A1: feats = LayerNorm(PE_sine(xyz) + W_e (xyz - center[cloud]) + b_e)
  * Replaces models/pointnet.py:45-48 (+ models/transformer.py:157-179).  xyz [rows,3] packed;
@@ -229,6 +234,7 @@ typedef struct {
     int32_t e_xq, e_xkv, e_wqkv, e_wq, e_wkv, e_wm_g, e_w1_g, e_w2_g;
     int32_t e_k, e_v; /* of K' = elu(k) + 1 and of V in the projection's K^T V epilogue */
     scream_tail_exps_t tail_exps;
+    int32_t tail_next_q; /* the tail image carries the NEXT layer's query projection (scream_pack_tail, Wq_next) */
 } scream_layer_t;
 
 typedef struct {

@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SCREAM_LIB=<path>: load that build instead (A/B runs of two builds on the same GPU box; never built automatically)
 LIB_PATH = os.environ.get("SCREAM_LIB") or os.path.join(_HERE, "libscream_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -25,13 +25,13 @@ SPLIT_H1, SPLIT_H2, SPLIT_BF3 = 1, 2, 3
 
 
 class TailExpsT(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("e_att", "e_wm", "e_m1", "e_w1", "e_h", "e_w2")]
+    _fields_ = [(n, C.c_int32) for n in ("e_att", "e_wm", "e_m1", "e_w1", "e_h", "e_w2", "e_y", "e_wq")]
 
 
 class LayerT(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("wqkv", "wq", "wkv", "wm", "w1", "w2", "g1", "b1", "g2", "b2", "tail")] +
                 [(n, C.c_int32) for n in ("e_xq", "e_xkv", "e_wqkv", "e_wq", "e_wkv", "e_wm_g", "e_w1_g", "e_w2_g", "e_k", "e_v")] +
-                [("tail_exps", TailExpsT)])
+                [("tail_exps", TailExpsT), ("tail_next_q", C.c_int32)])
 
 
 class ModelT(C.Structure):
@@ -61,11 +61,11 @@ SIGNATURES = {
     "scream_pack_w_split": (C.c_int, [V, I32, I32, I32, I32, V, V]),
     "scream_gemm_split_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, I32, V, V, I64, V, V, I32, I32, I32, I32, V]),
     "scream_gemm_qkv_split_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, V, V, V, I64, V, I32, I32, I32, I32, I32, I32, V]),
-    "scream_tail_image_bytes": (C.c_int64, [I32]),
+    "scream_tail_image_bytes": (C.c_int64, [I32, I32]),
     "scream_kv_image_bytes": (C.c_int64, []),
-    "scream_pack_tail": (C.c_int, [V, V, V, I32, C.POINTER(TailExpsT), V, V]),
+    "scream_pack_tail": (C.c_int, [V, V, V, V, I32, C.POINTER(TailExpsT), V, V]),
     "scream_kv_finalize_x3": (C.c_int, [V, V, V, I64, I32, I32, V, I32, I64, I64, V]),
-    "scream_layer_tail_f32": (C.c_int, [V, V, V, I32, V, V, V, V, V, V, V, V, I64, I32, C.POINTER(TailExpsT), V]),
+    "scream_layer_tail_f32": (C.c_int, [V, V, V, I32, V, V, V, V, V, V, V, V, V, I64, I32, C.POINTER(TailExpsT), V]),
     "scream_act_layout": (C.c_int, [V, V, I64, I32, V]),
     "scream_pe_embed_ln": (C.c_int, [V, V, V, V, V, V, V, V, V, I64, V]),
     "scream_pe_embed_ln_frag": (C.c_int, [V, V, V, V, V, V, V, V, V, I64, V]),

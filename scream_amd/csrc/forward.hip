@@ -132,8 +132,9 @@ int mha_tail(const Ctx& c, const scream_layer_t& L, const Workspace& w, const fl
 // Self attention over packed rows [row0, row0 + rows) whose clouds are [cloud_begin, cloud_begin + n_clouds)
 // (transformer.py:74-90 with q = k = v).  x / y are the full feature buffers (row 0 = packed row 0).
 // The q/k/v projection reduces K^T V in its epilogue, so K' and V never reach HBM.
+// next_q: the tail image carries the next (cross) layer's query projection -- Q' of that layer is written over this layer's (w.q)
 int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x,
-             float* y, int64_t row0, int64_t rows, int32_t cloud_begin, int32_t n_clouds) {
+             float* y, int64_t row0, int64_t rows, int32_t cloud_begin, int32_t n_clouds, bool next_q = false) {
     const float* xr = x + row0 * D;
     float* qr = w.q + row0 * D;
     float* kvp = w.kvp + row0 / SCREAM_ROW_TILE * SCREAM_NHEAD * KV_ELEMS;
@@ -143,9 +144,10 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
             Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
             TRY(scream_kv_finalize_x3(kvp, b.cloud_row0, b.cloud_len, row0, cloud_begin, n_clouds, w.kvimg, 1, 0, 0, c.st));
         }
-        Scope sc(c.tr, TR_TAIL_FUSED, rows, 9 * D, D, c.st);  // merge (256) + FFN up and down (2 x 1024) output columns per row
+        // merge (256) + FFN up and down (2 x 1024) (+ the next layer's query projection, 256) output columns per row
+        Scope sc(c.tr, TR_TAIL_FUSED, rows, (next_q ? 10 : 9) * D, D, c.st);
         return scream_layer_tail_f32(qr, w.kvimg, b.tile_cloud + row0 / SCREAM_ROW_TILE, 0, b.cloud_len, xr, L.tail, L.g1,
-                                     L.b1, L.g2, L.b2, y + row0 * D, rows, c.split, &L.tail_exps, c.st);
+                                     L.b1, L.g2, L.b2, y + row0 * D, next_q ? qr : nullptr, rows, c.split, &L.tail_exps, c.st);
     }
     {
         Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
@@ -178,16 +180,18 @@ int cross_kv_all(const Ctx& c, const scream_model_t& m, const scream_batch_t& b,
 // Cross attention: queries from the source rows, keys/values from the frozen target rows (transformer.py:130).
 // kvimg_layer != NULL: this layer's target-side K^T V images were already built by cross_kv_all (image of target cloud j at
 // kvimg_layer + j * scream_kv_image_bytes()).
+// q_ready: Q' (w.q) was written by the layer tail of the self layer in front (scream_layer_t.tail_next_q)
 int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x_src,
-              const float* x_tgt, float* y, const char* kvimg_layer) {
+              const float* x_tgt, float* y, const char* kvimg_layer, bool q_ready = false) {
     const int64_t rs = b.rows_src, rt = b.rows_total - b.rows_src;
-    TRY(gemm(c, x_src, D, L.wq, w.q, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr, L.e_xq, L.e_wq,
-             c.frag ? (SCREAM_LAYOUT_A_FRAG | SCREAM_LAYOUT_C_FRAG) : 0));
+    if (!q_ready)
+        TRY(gemm(c, x_src, D, L.wq, w.q, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr, L.e_xq, L.e_wq,
+                 c.frag ? (SCREAM_LAYOUT_A_FRAG | SCREAM_LAYOUT_C_FRAG) : 0));
     if (c.frag && kvimg_layer) {
         Scope sc(c.tr, TR_TAIL_FUSED, rs, 9 * D, D, c.st);
         // tile_cloud holds source cloud i for the source tiles; its target cloud's image is entry i of this layer's block
         return scream_layer_tail_f32(w.q, kvimg_layer, b.tile_cloud, 0, b.cloud_len + b.n_pairs, x_src, L.tail, L.g1, L.b1, L.g2,
-                                     L.b2, y, rs, c.split, &L.tail_exps, c.st);
+                                     L.b2, y, nullptr, rs, c.split, &L.tail_exps, c.st);
     }
     TRY(gemm_qkv(c, x_tgt, L.wkv, nullptr, rt, 2 * D, 0, b, rs, w.kvp, L.e_xkv, L.e_wkv, L.e_k, L.e_v));
     if (c.frag) {
@@ -197,7 +201,7 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
         }
         Scope sc(c.tr, TR_TAIL_FUSED, rs, 9 * D, D, c.st);
         return scream_layer_tail_f32(w.q, w.kvimg, b.tile_cloud, b.n_pairs, b.cloud_len, x_src, L.tail, L.g1, L.b1, L.g2, L.b2,
-                                     y, rs, c.split, &L.tail_exps, c.st);
+                                     y, nullptr, rs, c.split, &L.tail_exps, c.st);
     }
     {
         Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
@@ -212,8 +216,8 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
 
 }  // namespace
 
-extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi12"; }
-extern "C" int scream_abi_version(void) { return 12; }
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi13"; }
+extern "C" int scream_abi_version(void) { return 13; }
 
 extern "C" void* scream_trace_create(int32_t capacity) {
     if (capacity <= 0) return nullptr;
@@ -326,9 +330,10 @@ extern "C" int scream_forward(const scream_model_t* model, const scream_batch_t*
     for (int i = 0; i < 2 * m.n_cross; ++i) {  // pointnet.py:53-57
         const scream_layer_t& L = m.layers_host[m.n_self + i];
         if (i % 2 == 0) {
-            TRY(mha_self(c, L, b, w, cur, nxt, 0, rs, 0, b.n_pairs));
+            TRY(mha_self(c, L, b, w, cur, nxt, 0, rs, 0, b.n_pairs, c.frag && L.tail_next_q));
         } else {
-            TRY(mha_cross(c, L, b, w, cur, x_tgt, nxt, batched_kv ? w.kvimg_cross + (i / 2) * w.kvimg_cross_stride : nullptr));
+            const bool q_ready = c.frag && m.layers_host[m.n_self + i - 1].tail_next_q;
+            TRY(mha_cross(c, L, b, w, cur, x_tgt, nxt, batched_kv ? w.kvimg_cross + (i / 2) * w.kvimg_cross_stride : nullptr, q_ready));
         }
         float* t = cur;
         cur = nxt;

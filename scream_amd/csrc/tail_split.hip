@@ -90,6 +90,7 @@ extern "C" int scream_tail_stamps_read(long long* host) {
 namespace {
 
 constexpr int TAIL_STAGES = 72;
+constexpr int NEXT_Q_STAGES = 8;  // tail_kernel<SP, true>: the NEXT layer's 256 -> 256 query projection rides behind norm2 (below)
 constexpr int KV_PLANES_BYTES = 8 * 3 * 2 * 1024;            // per cloud: [head][plane][step][lane][8] bf16
 constexpr int KV_IMAGE_BYTES = KV_PLANES_BYTES + 8 * 32 * 4;  // + Ksum [head][32] fp32
 
@@ -107,6 +108,8 @@ struct TailScales {
     float ch;     // 2^(e_h - e_w1 - e_m1): FFN-up accumulator -> scaled hidden activation
     float c2;     // 2^(e_w2 + e_h): unit of the FFN-down accumulators
     float eps2;   // 1e-5 c2^2
+    float s_y;    // NQ: 2^e_y, the block OUTPUT as the operand of the next layer's query projection
+    float cq;     // NQ: 2^-(e_y + e_wq): accumulator of that projection -> q
 };
 
 // merge stage h (h >= 1): which quarter of the x-segment add rides in group g (-1: none) -- the last four groups of
@@ -121,7 +124,11 @@ __device__ __forceinline__ constexpr int xadd_slot(int h, int g, int nd) {
     return -1;
 }
 
-template <class SP>
+// NQ (round 3, fp16 splits): the image carries eight more stages, Wq of the NEXT layer (a cross layer: its queries are this
+// block's output rows, models/transformer.py:130), and the kernel ends every tile with  Q'_next = elu(y . Wq^T) + 1  -- y is in
+// registers in operand layout the moment norm2 is done, so the separate projection launch (x re-read, re-split, one more launch
+// per layer with its partial last round) disappears.  q_next may alias Q: a tile reads its own rows of Q long before it writes them.
+template <class SP, bool NQ>
 __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q,      // fragment-major [M, 256]
                                                      const char* __restrict__ kvimg,   // [n_clouds][KV_IMAGE_BYTES]
                                                      const int32_t* __restrict__ tile_cloud, int kv_cloud_offset,
@@ -131,7 +138,10 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
                                                      const float* __restrict__ g1, const float* __restrict__ b1,
                                                      const float* __restrict__ g2, const float* __restrict__ b2,
                                                      float* __restrict__ y,            // fragment-major [M, 256]
+                                                     float* q_next,                    // NQ: fragment-major [M, 256] (may alias Q)
                                                      int n_tiles, TailScales sc) {
+    static_assert(!NQ || SP::SCALED, "the next-layer query projection is built for the fp16 splits");
+    constexpr int N_STAGES = TAIL_STAGES + (NQ ? NEXT_Q_STAGES : 0);
     typedef typename SP::vec V;
     constexpr int NP = SP::NP;
     constexpr int STAGE = stage_bytes<SP>();
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
     // kernel was spilled by hipcc and reloaded from scratch in EVERY stage -- behind a vmcnt(0) that drained the ring.
     auto dma_piece = [&](unsigned q, int u) {
         if ((T_ABLATE & 1) && q >= 2) return;
-        const unsigned src = q % (unsigned)TAIL_STAGES, slot = q % (unsigned)T_SLOTS;
+        const unsigned src = q % (unsigned)N_STAGES, slot = q % (unsigned)T_SLOTS;
         const char* sbase = Wimg + (size_t)src * STAGE + (wave * PIECES + (u & ~3)) * 1024;
         dma_1k(sbase + v_lane16, smem + slot * STAGE + (wave * PIECES + (u & ~3)) * 1024, u & 3);
     };
@@ -333,7 +343,9 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
             constexpr bool RIDE = h >= 1 && h <= 6;
             // stage 0 of a tile: everything older was drained at the end of the previous tile (only its y stores may
             // still be in flight, and nothing of this stage depends on them)
-            if (h == 0) lds_only_barrier(); else ring_barrier<PIECES>();
+            // (NQ: the previous tile ended in ring stages whose last chunk's STORES are the youngest operations in the queue -- a counted
+            // wait is only sound among loads, so this one barrier per tile drains)
+            if (h == 0) { if (NQ) ring_barrier<0>(); else lds_only_barrier(); } else ring_barrier<PIECES>();
             TMARK(h);  // T_STAMPS builds: marks 0-7 = the tops of the merge stages
             __builtin_amdgcn_sched_barrier(0);
             f32x4 (&x_prev)[4] = (h & 1) ? xs : xs2;   // segment h - 1 (landed: requested by stage h - 1)
@@ -604,6 +616,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
 
         TSTAMP(4);  // after the open apply of the next tile's head 1
         // ---- y = LayerNorm2(x + ffn) (the residual is already in the accumulators), stored fragment-major ------------
+        V yp[NQ ? 16 : 1][NP];  // NQ: the planes of y
         {
             float sum = 0.f;
 #pragma unroll
@@ -628,14 +641,94 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
 #pragma unroll
             for (int b = 0; b < 8; ++b)
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const f32x4 g4 = ld4(gp + 32 * b + 8 * a), b4 = ld4(bp + 32 * b + 8 * a);
-                    f32x4 o;
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    f32x4 o2[2];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = acc[b][4 * a + k] * rstd * g4[k] + b4[k];
-                    // one contiguous 1 KiB per wave instruction
-                    if (!(T_ABLATE & (16 | 128)) || o[0] + o[1] + o[2] + o[3] == 123.456f) *reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256) = o;
+                    for (int a2 = 0; a2 < 2; ++a2) {
+                        const int a = 2 * s2 + a2;
+                        const f32x4 g4 = ld4(gp + 32 * b + 8 * a), b4 = ld4(bp + 32 * b + 8 * a);
+                        f32x4 o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = acc[b][4 * a + k] * rstd * g4[k] + b4[k];
+                        // one contiguous 1 KiB per wave instruction
+                        if (!(T_ABLATE & (16 | 128)) || o[0] + o[1] + o[2] + o[3] == 123.456f) *reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256) = o;
+                        o2[a2] = o;
+                    }
+                    if (NQ) split8<SP>(o2[0] * sc.s_y, o2[1] * sc.s_y, yp[NQ ? 2 * b + s2 : 0]);  // B operand of the query stages below
                 }
+        }
+        if constexpr (NQ) {
+            // ---- Q'_next = elu(y . Wq^T) + 1: eight ring stages, chunk j = output features 32 j .. 32 j + 31 (an FFN-up stage with y's
+            // planes as the operand), accumulated alternately in hq[0 / 1].  Chunk j - 1 -- complete once stage j has flushed its deferred
+            // groups -- gets its elu in stage j's first eight groups and is stored behind them, BEFORE the stage issues its weight
+            // pieces (second half of the groups): the next barrier's counted wait then leaves exactly those pieces in flight, and
+            // every store is older than every load a counted wait has to cover (stores retire out of order against loads).
+            f32x16 hq[2];
+            f32x4 oq[4];
+            float* qg = q_next + grp + lane * 4;
+            auto elu_pair = [&](int k, const f32x16& h) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 2 * k + e;
+                    const float x = h[i] * sc.cq;
+                    oq[i >> 2][i & 3] = x > 0.f ? x + 1.0f : expf(x);  // elu(x) + 1 == exp(x), x <= 0
+                }
+            };
+            auto store_chunk = [&](int j) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    if (!(T_ABLATE & (16 | 128)) || oq[a][0] == 123.456f) *reinterpret_cast<f32x4*>(qg + (j * 4 + a) * 256) = oq[a];
+            };
+            constexpr int PP = (PIECES + NG - 9) / (NG - 8);  // weight pieces per group from group 8 on
+            auto stage_q = [&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                if (j == 0) lds_only_barrier(); else ring_barrier<PIECES>();  // (stage 0: the queue was drained in front of norm2)
+                __builtin_amdgcn_sched_barrier(0);
+                const char* wb = smem + (q % T_SLOTS) * STAGE + lane * 16;
+                V wf[T_PF][NP];
+#pragma unroll
+                for (int g0 = 0; g0 < T_PF - 1; ++g0)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) wf[g0][p] = ld_frag<V>(wb + (p * 16 + g0) * 1024);
+                if (j > 0) {
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) mfma_group<SP, -1>(hq[(j + 1) & 1], wfd[i], yp[NG + i]);
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g + T_PF - 1 < 16) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p)
+                            (g + T_PF - 1 >= NG ? wfd[g + T_PF - 1 - NG][p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag<V>(wb + (p * 16 + g + T_PF - 1) * 1024);
+                    }
+                    if (j > 0 && g < 8) elu_pair(g, hq[(j + 1) & 1]);
+                    if (g == 8) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (j > 0) store_chunk(j - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (g >= 8) {
+#pragma unroll
+                        for (int u = (g - 8) * PP; u < (g - 7) * PP; ++u)
+                            if (u < PIECES) dma_piece(q + 2, u);
+                    }
+                    mfma_group<SP, 8>(hq[j & 1], wf[g % T_PF], yp[g], g == 0);
+                }
+                ++q;
+            };
+            stage_q(std::integral_constant<int, 0>{});
+            stage_q(std::integral_constant<int, 1>{});
+            stage_q(std::integral_constant<int, 2>{});
+            stage_q(std::integral_constant<int, 3>{});
+            stage_q(std::integral_constant<int, 4>{});
+            stage_q(std::integral_constant<int, 5>{});
+            stage_q(std::integral_constant<int, 6>{});
+            stage_q(std::integral_constant<int, 7>{});
+#pragma unroll
+            for (int i = 0; i < ND; ++i) mfma_group<SP, -1>(hq[1], wfd[i], yp[NG + i]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) elu_pair(k, hq[1]);
+            store_chunk(7);
         }
         TSTAMP(5);  // tile end
         TMARKS_FLUSH();
@@ -689,11 +782,13 @@ __global__ __launch_bounds__(256) void act_layout_kernel(const float* __restrict
 // m = lane & 31 of fragment frag = 2 blk + s2 is output feature 32 blk + m (down / merge) or hidden unit 32 c + m (up); its
 // eight values are contraction indices chunk_k(s2, half, 0 .. 7) of the stage's 32-wide chunk.  SplitH2: every matrix is
 // multiplied by its exact 2^e first.  One thread per (stage, fragment, lane).
+// Wq_next != NULL: eight more stages, chunk j of the next layer's query projection [256][256] laid out like an up stage.
 template <class SP>
 __global__ void pack_tail_kernel(const float* __restrict__ Wm, const float* __restrict__ W1, const float* __restrict__ W2,
-                                 float s_wm, float s_w1, float s_w2, typename SP::vec* __restrict__ out) {
+                                 const float* __restrict__ Wq_next, float s_wm, float s_w1, float s_w2, float s_wq,
+                                 typename SP::vec* __restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= TAIL_STAGES * 16 * 64) return;
+    if (t >= (TAIL_STAGES + (Wq_next ? NEXT_Q_STAGES : 0)) * 16 * 64) return;
     const int lane = t & 63, frag = (t >> 6) & 15, stage = t >> 10;
     const int m = lane & 31, half = lane >> 5;
     float v[8];
@@ -702,6 +797,10 @@ __global__ void pack_tail_kernel(const float* __restrict__ Wm, const float* __re
         s = s_wm;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = Wm[(int64_t)(32 * (frag >> 1) + m) * 256 + 32 * stage + chunk_k(frag & 1, half, j)];
+    } else if (stage >= TAIL_STAGES) {
+        s = s_wq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Wq_next[(int64_t)(32 * (stage - TAIL_STAGES) + m) * 256 + 32 * (frag >> 1) + chunk_k(frag & 1, half, j)];
     } else {
         const int st = stage - 8;
         const bool up = st == 0 || (st < 63 && (st & 1));
@@ -798,33 +897,37 @@ bool tail_scales(const scream_tail_exps_t* ex, TailScales* sc) {
     sc->ch = exp2i(eh);
     sc->c2 = exp2i(e2);
     sc->eps2 = 1e-5f * exp2i(2 * e2);
+    if (ex->e_y < -40 || ex->e_y > 40 || ex->e_wq < -40 || ex->e_wq > 40) return false;
+    sc->s_y = exp2i(ex->e_y);
+    sc->cq = exp2i(-ex->e_y - ex->e_wq);
     return true;
 }
 
 }  // namespace
 
-extern "C" int64_t scream_tail_image_bytes(int32_t split) {
-    if (!split_ok(split)) return SCREAM_EINVAL;
-    return (int64_t)TAIL_STAGES * split * 16 * 1024;
+extern "C" int64_t scream_tail_image_bytes(int32_t split, int32_t with_next_q) {
+    if (!split_ok(split) || (with_next_q && split == SCREAM_SPLIT_BF3)) return SCREAM_EINVAL;
+    return (int64_t)(TAIL_STAGES + (with_next_q ? NEXT_Q_STAGES : 0)) * split * 16 * 1024;
 }
 extern "C" int64_t scream_kv_image_bytes(void) { return KV_IMAGE_BYTES; }
 
-extern "C" int scream_pack_tail(const float* Wm, const float* W1, const float* W2, int32_t split, const scream_tail_exps_t* exps,
-                                void* image, void* stream) {
+extern "C" int scream_pack_tail(const float* Wm, const float* W1, const float* W2, const float* Wq_next, int32_t split,
+                                const scream_tail_exps_t* exps, void* image, void* stream) {
     SCREAM_REQUIRE(Wm && W1 && W2 && image && split_ok(split), SCREAM_EINVAL);
+    SCREAM_REQUIRE(!Wq_next || split != SCREAM_SPLIT_BF3, SCREAM_EUNSUPPORTED);
     SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, SCREAM_EINVAL);
-    const dim3 grid(TAIL_STAGES * 16 * 64 / 256), block(256);
+    const dim3 grid((TAIL_STAGES + (Wq_next ? NEXT_Q_STAGES : 0)) * 16 * 64 / 256), block(256);
     if (split != SCREAM_SPLIT_BF3) {
         TailScales sc;
         SCREAM_REQUIRE(tail_scales(exps, &sc), SCREAM_EINVAL);
         if (split == SCREAM_SPLIT_H2)
-            pack_tail_kernel<SplitH2><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, exp2i(exps->e_wm), exp2i(exps->e_w1), exp2i(exps->e_w2),
-                                                                             reinterpret_cast<f16x8*>(image));
+            pack_tail_kernel<SplitH2><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, Wq_next, exp2i(exps->e_wm), exp2i(exps->e_w1),
+                                                                             exp2i(exps->e_w2), exp2i(exps->e_wq), reinterpret_cast<f16x8*>(image));
         else
-            pack_tail_kernel<SplitH1><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, exp2i(exps->e_wm), exp2i(exps->e_w1), exp2i(exps->e_w2),
-                                                                             reinterpret_cast<f16x8*>(image));
+            pack_tail_kernel<SplitH1><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, Wq_next, exp2i(exps->e_wm), exp2i(exps->e_w1),
+                                                                             exp2i(exps->e_w2), exp2i(exps->e_wq), reinterpret_cast<f16x8*>(image));
     } else {
-        pack_tail_kernel<SplitBf3><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, 1.f, 1.f, 1.f, reinterpret_cast<bf16x8*>(image));
+        pack_tail_kernel<SplitBf3><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, nullptr, 1.f, 1.f, 1.f, 1.f, reinterpret_cast<bf16x8*>(image));
     }
     SCREAM_LAUNCH_CHECK();
     return 0;
@@ -845,35 +948,46 @@ extern "C" int scream_kv_finalize_x3(const float* kv_partial, const int32_t* clo
     return 0;
 }
 
+namespace {
+template <class SP, bool NQ>
+void launch_tail(unsigned grid, hipStream_t st, const float* Q, const void* kv_image, const int32_t* tile_cloud, int32_t kv_cloud_offset,
+                 const int32_t* cloud_len, const float* x, const void* tail_image, const float* g1, const float* b1, const float* g2,
+                 const float* b2, float* y, float* q_next, int tiles, const TailScales& sc) {
+    tail_kernel<SP, NQ><<<dim3(grid), dim3(TT), 0, st>>>(Q, reinterpret_cast<const char*>(kv_image), tile_cloud, kv_cloud_offset, cloud_len, x,
+                                                         reinterpret_cast<const char*>(tail_image), g1, b1, g2, b2, y, q_next, tiles, sc);
+}
+}  // namespace
+
 extern "C" int scream_layer_tail_f32(const float* Q, const void* kv_image, const int32_t* tile_cloud,
                                      int32_t kv_cloud_offset, const int32_t* cloud_len, const float* x,
                                      const void* tail_image, const float* g1, const float* b1, const float* g2,
-                                     const float* b2, float* y, int64_t M, int32_t split, const scream_tail_exps_t* exps,
-                                     void* stream) {
+                                     const float* b2, float* y, float* q_next, int64_t M, int32_t split,
+                                     const scream_tail_exps_t* exps, void* stream) {
     SCREAM_REQUIRE(Q && kv_image && tile_cloud && cloud_len && x && tail_image && g1 && b1 && g2 && b2 && y && split_ok(split), SCREAM_EINVAL);
     SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0, SCREAM_EUNSUPPORTED);
     SCREAM_REQUIRE(((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(kv_image) | reinterpret_cast<uintptr_t>(x) |
                      reinterpret_cast<uintptr_t>(tail_image) | reinterpret_cast<uintptr_t>(g1) | reinterpret_cast<uintptr_t>(b1) |
-                     reinterpret_cast<uintptr_t>(g2) | reinterpret_cast<uintptr_t>(b2) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, SCREAM_EINVAL);
+                     reinterpret_cast<uintptr_t>(g2) | reinterpret_cast<uintptr_t>(b2) | reinterpret_cast<uintptr_t>(y) |
+                     reinterpret_cast<uintptr_t>(q_next)) & 15) == 0, SCREAM_EINVAL);
     SCREAM_REQUIRE(x != y, SCREAM_EINVAL);  // the residual of a row is read twice, long after its neighbours were written
-    TailScales sc{1.f, 1.f, 1e-5f, 1.f, 1.f, 1.f, 1e-5f};
+    // q_next (the image then has its eight query stages): fp16 splits only; it may be Q itself, never x or y
+    SCREAM_REQUIRE(!q_next || (split != SCREAM_SPLIT_BF3 && q_next != x && q_next != y), SCREAM_EINVAL);
+    TailScales sc{1.f, 1.f, 1e-5f, 1.f, 1.f, 1.f, 1e-5f, 1.f, 1.f};
     if (split != SCREAM_SPLIT_BF3) SCREAM_REQUIRE(tail_scales(exps, &sc), SCREAM_EINVAL);
     const int64_t tiles = M / SCREAM_ROW_TILE;
     if (tiles == 0) return 0;
     SCREAM_REQUIRE(tiles < (1ll << 31), SCREAM_EUNSUPPORTED);
     const unsigned grid = tiles < T_MAX_GRID ? (unsigned)tiles : (unsigned)T_MAX_GRID;
-    if (split == SCREAM_SPLIT_H2)
-        tail_kernel<SplitH2><<<dim3(grid), dim3(TT), 0, as_stream(stream)>>>(Q, reinterpret_cast<const char*>(kv_image), tile_cloud,
-                                                                             kv_cloud_offset, cloud_len, x, reinterpret_cast<const char*>(tail_image),
-                                                                             g1, b1, g2, b2, y, (int)tiles, sc);
-    else if (split == SCREAM_SPLIT_H1)
-        tail_kernel<SplitH1><<<dim3(grid), dim3(TT), 0, as_stream(stream)>>>(Q, reinterpret_cast<const char*>(kv_image), tile_cloud,
-                                                                             kv_cloud_offset, cloud_len, x, reinterpret_cast<const char*>(tail_image),
-                                                                             g1, b1, g2, b2, y, (int)tiles, sc);
-    else
-        tail_kernel<SplitBf3><<<dim3(grid), dim3(TT), 0, as_stream(stream)>>>(Q, reinterpret_cast<const char*>(kv_image), tile_cloud,
-                                                                              kv_cloud_offset, cloud_len, x, reinterpret_cast<const char*>(tail_image),
-                                                                              g1, b1, g2, b2, y, (int)tiles, sc);
+    hipStream_t st = as_stream(stream);
+#define TAIL_ARGS grid, st, Q, kv_image, tile_cloud, kv_cloud_offset, cloud_len, x, tail_image, g1, b1, g2, b2, y, q_next, (int)tiles, sc
+    if (split == SCREAM_SPLIT_H2) {
+        if (q_next) launch_tail<SplitH2, true>(TAIL_ARGS); else launch_tail<SplitH2, false>(TAIL_ARGS);
+    } else if (split == SCREAM_SPLIT_H1) {
+        if (q_next) launch_tail<SplitH1, true>(TAIL_ARGS); else launch_tail<SplitH1, false>(TAIL_ARGS);
+    } else {
+        launch_tail<SplitBf3, false>(TAIL_ARGS);
+    }
+#undef TAIL_ARGS
     SCREAM_LAUNCH_CHECK();
     return 0;
 }

@@ -21,7 +21,8 @@ from torch.utils.data import Dataset
 from . import dist as sdist
 from . import synthetic
 from .data import normalize_pair
-from .evaluate import register_items
+from . import lanes as _lanes
+from .evaluate import IN_FLIGHT, register_items_async
 from .geometry import processbar
 
 SKIP_ITEMS = (124, 142)  # evaluate_kitti.py:32-34
@@ -67,7 +68,7 @@ def _strip6(item):
 @torch.no_grad()
 def evaluate(net, loader, dis_thresh: float = KITTI_DIS_THRESH, icp_thresh: float = KITTI_ICP_DIST, icp="gpu",
              icp_iters: int = KITTI_ICP_ITERS, batch_pairs: int = 8, skip: Sequence[int] = SKIP_ITEMS,
-             verbose: bool = True, pred_hook=None, autocast: bool = False):
+             verbose: bool = True, pred_hook=None, autocast: bool = False, in_flight: int = IN_FLIGHT):
     """evaluate_kitti.py:23-103.  Pairs are sharded round-robin over ranks when torch.distributed is initialised.
     autocast=True: the forward's matrix products in fp16 with fp32 accumulation, like the reference's `with autocast()`
     (:37) -- a labelled reduced-precision mode, tolerance-tested against the default path, never the default."""
@@ -75,7 +76,7 @@ def evaluate(net, loader, dis_thresh: float = KITTI_DIS_THRESH, icp_thresh: floa
         saved = net.__dict__.get("gemm_backend")  # (instance override, if any; the class attribute is the default)
         net.gemm_backend = "h1"
         try:
-            return evaluate(net, loader, dis_thresh, icp_thresh, icp, icp_iters, batch_pairs, skip, verbose, pred_hook, False)
+            return evaluate(net, loader, dis_thresh, icp_thresh, icp, icp_iters, batch_pairs, skip, verbose, pred_hook, False, in_flight)
         finally:
             if saved is None:
                 del net.gemm_backend
@@ -86,19 +87,33 @@ def evaluate(net, loader, dis_thresh: float = KITTI_DIS_THRESH, icp_thresh: floa
     ids = [i for i in range(len(dataset)) if i not in skip]
     mine = ids[rank::world]
     rows = []
-    for b0 in range(0, len(mine), batch_pairs):
-        bid = mine[b0:b0 + batch_pairs]
-        its = [_strip6(dataset[i]) for i in bid]
-        centers = [-(it[2].t() @ it[3]).reshape(3) for it in its]  # evaluate_kitti.py:39
-        T, T_gt, re, te, loss = register_items(net, its, centers, bid, "tgt", dis_thresh, icp, icp_thresh, icp_iters,
-                                               pred_hook=pred_hook)
+
+    def collect(fin, bid, n_done):
+        T, T_gt, re, te, loss = fin()
         for k, i in enumerate(bid):
             r = np.zeros(sdist.ROW_WIDTH)
             r[sdist.COL_PAIR], r[sdist.COL_SUCCESS] = i, float(re[k] <= 5.0 and te[k] <= 2.0)
             r[sdist.COL_RE], r[sdist.COL_TE], r[sdist.COL_LOSS] = re[k], te[k], loss[k]
             rows.append(r)
         if verbose and rank == 0:
-            print("\r%s  re: %.5f  te: %.5f" % (processbar(min(b0 + batch_pairs, len(mine)), len(mine)), re[-1], te[-1]), end="")
+            print("\r%s  re: %.5f  te: %.5f" % (processbar(n_done, len(mine)), re[-1], te[-1]), end="")
+
+    # like evaluate_loader (scream_amd/evaluate.py): in_flight batches enqueued, each whole on its own stream, collected in order
+    dev = next(net.parameters()).device
+    in_flight = max(1, int(in_flight))
+    streams = _lanes.lane_streams(dev, in_flight) if dev.type == "cuda" else [None] * in_flight
+    pending = []
+    for k, b0 in enumerate(range(0, len(mine), batch_pairs)):
+        bid = mine[b0:b0 + batch_pairs]
+        its = [_strip6(dataset[i]) for i in bid]
+        centers = [-(it[2].t() @ it[3]).reshape(3) for it in its]  # evaluate_kitti.py:39
+        fin = register_items_async(net, its, centers, bid, "tgt", dis_thresh, icp, icp_thresh, icp_iters, pred_hook=pred_hook,
+                                   stream=streams[k % in_flight])
+        pending.append((fin, bid, min(b0 + batch_pairs, len(mine))))
+        if len(pending) >= in_flight:
+            collect(*pending.pop(0))
+    for pd in pending:
+        collect(*pd)
     allrows = sdist.all_gather_rows(np.array(rows).reshape(-1, sdist.ROW_WIDTH))
     n = max(allrows.shape[0], 1)
     ok = allrows[:, sdist.COL_SUCCESS] > 0

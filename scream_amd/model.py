@@ -106,11 +106,16 @@ class PointTransformer(nn.Module):
     # K^T V images in one) instead of once per cross layer; SCREAM_BATCHED_CROSS_KV=0 keeps the per-layer launches
     batched_cross_kv = os.environ.get("SCREAM_BATCHED_CROSS_KV", "1") != "0"
 
+    # fused tail on an fp16 split only: the layer tail of every cross-stage SELF layer also projects the queries of the cross
+    # layer behind it (eight more ring stages at the end of every tile; csrc/tail_split.hip, NQ) -- six launches fewer per forward;
+    # SCREAM_FUSE_NEXT_Q=0 keeps the separate projection launches
+    fuse_next_q = os.environ.get("SCREAM_FUSE_NEXT_Q", "1") != "0"
+
     def _fused_cfg(self, split) -> bool:
         return bool(split and self.fused_tail)
 
     def _signature(self):
-        return (self.gemm_backend, self.fused_tail, self.batched_cross_kv) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.gemm_backend, self.fused_tail, self.batched_cross_kv, self.fuse_next_q) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _layer_inputs(self):
         """(in_q, in_kv) per layer of _layer_modules() [+ per layer of _stem_tgt_modules()] and the coordinate MLP's input:
@@ -166,6 +171,9 @@ class PointTransformer(nn.Module):
         ins, tgt_ins, coor_in = self._layer_inputs()
         layers = (_lib.LayerT * len(mods))()
         tgt_layers = (_lib.LayerT * max(len(tgt_mods), 1))()
+        ns = self.self_layer_num
+        # the cross layer behind every cross-stage self layer, when its query projection rides in that layer's tail
+        next_cross = {id(mods[i]): i + 1 for i in range(ns, len(mods) - 1, 2)} if (fp16_split and self.fused_tail and self.fuse_next_q) else {}
         for L, m, (in_q, in_kv) in list(zip(layers, mods, ins)) + list(zip(tgt_layers, tgt_mods, tgt_ins)):
             # [q | k heads 0-3 | v heads 0-3 | k heads 4-7 | v heads 4-7]: a 256-wide GEMM tile then holds K and V of
             # four heads for the same tokens, which is what the fused K^T V epilogue needs (include/scream_hip.h)
@@ -176,11 +184,18 @@ class PointTransformer(nn.Module):
             L.wkv, L.e_wkv = dev_mat(wkv)
             ex = scales.layer_exps(m, in_q, in_kv) if fp16_split else {}
             L.e_xq, L.e_xkv, L.e_k, L.e_v = ex.get("e_xq", 0), ex.get("e_xkv", 0), ex.get("e_k", 0), ex.get("e_v", 0)
+            wq_next = None
+            if id(m) in next_cross:  # this block's output (a LayerNorm2 output) is the operand of the next layer's q_proj
+                nxt = next_cross[id(m)]
+                wq_next = mods[nxt].q_proj.weight
+                ex.update(e_y=scales.exp_for(scales.ln_bound(*ins[nxt][0])), e_wq=scales.w_exp(wq_next))
             L.tail_exps = ops.tail_exps(**ex)
             L.tail = None
+            L.tail_next_q = int(wq_next is not None)
             if split and self.fused_tail:  # one launch for everything behind the projections (scream_layer_tail_f32)
                 f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32)
-                img = ops.pack_tail(f32(m.merge.weight), f32(m.mlp[0].weight), f32(m.mlp[2].weight), split, L.tail_exps)
+                img = ops.pack_tail(f32(m.merge.weight), f32(m.mlp[0].weight), f32(m.mlp[2].weight), split, L.tail_exps,
+                                    Wq_next=None if wq_next is None else f32(wq_next))
                 keep.append(img.data)
                 L.tail = img.data_ptr()
                 L.wm, L.w1, L.w2 = None, None, None

@@ -806,6 +806,78 @@ def test_fused_layer_tail_many_tiles_equals_unfused_path(split):
     assert torch.equal(ops.layer_tail(Qf, kvi, tc, 0, clen, xf, img, g1, b1, g2, b2), yf)  # deterministic
 
 
+def test_layer_tail_with_the_next_layers_query_projection():
+    """tail_kernel<SplitH2, NQ>: the image carries Wq of the NEXT layer and every tile ends with Q'_next = elu(y Wq^T) + 1 written
+    over its own rows of Q (258 row tiles on 256 persistent blocks, ragged clouds).  y is bit-identical to the plain kernel's;
+    Q'_next equals the projection GEMM of that y (same products, another summation order inside the matrix unit); the bf16 split
+    refuses the image."""
+    g_ = torch.Generator().manual_seed(5)
+    n_clouds, rows = 24, 33024
+    bounds = torch.linspace(0, rows // 128, n_clouds + 1).round().int()
+    lens, row0, tiles = [], [], []
+    for c in range(n_clouds):
+        t0, t1 = int(bounds[c]), int(bounds[c + 1])
+        row0.append(t0 * 128)
+        lens.append((t1 - t0) * 128 - int(torch.randint(0, 127, (1,), generator=g_)))
+        tiles += [c] * (t1 - t0)
+    x = torch.randn(rows, 256, generator=g_)
+    sd = make_state_dict(6, 256, 1, 1)
+    pre = "stem.0."
+    q, k, v = (sd[pre + "%s_proj.weight" % n] for n in "qkv")
+    W = torch.cat([q, k[:128], v[:128], k[128:], v[128:]], dim=0)
+    Wq_next = sd["cross.1.layer.q_proj.weight"]
+    tc, crow0, clen = dev(torch.tensor(tiles, dtype=torch.int32)), dev(torch.tensor(row0, dtype=torch.int32)), dev(torch.tensor(lens, dtype=torch.int32))
+    g1, b1, g2, b2 = (dev(sd[pre + n]) for n in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"))
+    xf = ops.act_layout(dev(x), True)
+    SPL = ops.SPLIT_H2
+    Qf, part = ops.gemm_qkv(xf, ops.pack_w(dev(W), SPL), 256, tc, crow0, clen, 0, ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG)
+    kvi = ops.kv_finalize_x3(part, crow0, clen, 0, 0, n_clouds, n_clouds)
+    exd = scales.tail_exps(sd[pre + "merge.weight"], sd[pre + "mlp.0.weight"], sd[pre + "mlp.2.weight"], sd[pre + "norm1.weight"],
+                           sd[pre + "norm1.bias"], float((x @ v.t()).abs().max()) * 1.01)
+    plain = ops.pack_tail(dev(sd[pre + "merge.weight"]), dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"]), SPL, ops.tail_exps(**exd))
+    y_plain = ops.layer_tail(Qf, kvi, tc, 0, clen, xf, plain, g1, b1, g2, b2)
+    # y is a LayerNorm2 output: bounded by its gamma / beta, which is where the forward takes e_y from
+    e_y, e_wq = scales.exp_for(scales.ln_bound(sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])), scales.w_exp(Wq_next)
+    img = ops.pack_tail(dev(sd[pre + "merge.weight"]), dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"]), SPL,
+                        ops.tail_exps(e_y=e_y, e_wq=e_wq, **exd), Wq_next=dev(Wq_next))
+    assert img.next_q and img.data.numel() == 80 * 32 * 1024
+    from scream_amd._lib import ScreamHipError
+    valid = torch.zeros(rows, dtype=torch.bool)
+    for r0, n in zip(row0, lens):
+        valid[r0:r0 + n] = True
+    q_sep = torch.full_like(Qf, float("nan"))  # a buffer of its own
+    y = ops.layer_tail(Qf, kvi, tc, 0, clen, xf, img, g1, b1, g2, b2, q_next=q_sep)
+    assert torch.equal(y, y_plain)
+    want = ops.gemm_split(y, ops.pack_w(dev(Wq_next), SPL, e_wq), ops.EPI_ELU1, n_act=256, layout=ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG, a_exp=e_y)
+    torch.testing.assert_close(ops.act_layout(q_sep, False).cpu()[valid], ops.act_layout(want, False).cpu()[valid], rtol=2e-6, atol=2e-6)
+    q_inplace = Qf.clone()  # in place over Q: a tile reads its rows of Q long before it writes them
+    assert torch.equal(ops.layer_tail(q_inplace, kvi, tc, 0, clen, xf, img, g1, b1, g2, b2, q_next=q_inplace), y_plain)
+    assert torch.equal(ops.act_layout(q_inplace, False).cpu()[valid], ops.act_layout(q_sep, False).cpu()[valid])
+    with pytest.raises(AssertionError):
+        ops.layer_tail(Qf, kvi, tc, 0, clen, xf, plain, g1, b1, g2, b2, q_next=torch.empty_like(Qf))  # image without the stages
+    with pytest.raises(ScreamHipError):
+        ops.pack_tail(dev(sd[pre + "merge.weight"]), dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"]), ops.SPLIT_BF3, Wq_next=dev(Wq_next))
+
+
+def test_forward_with_and_without_the_fused_query_projection(golden):
+    """PointTransformer.fuse_next_q: the cross-stage self layers' tails also project the next layer's queries (six launches fewer).
+    Same products either way; the two forwards agree to fp32 rounding and both stay on the reference golden."""
+    from scream_amd.model import PointTransformer
+    sd = make_state_dict(0, 256, 2, 2)
+    g_ = torch.Generator().manual_seed(2)
+    src, tgt = torch.rand(700, 3, generator=g_) - 0.5, torch.rand(900, 3, generator=g_) - 0.5
+    outs = {}
+    for on in (True, False):
+        net = PointTransformer(256, 2, 2)
+        net.load_state_dict(sd)
+        net = net.to("cuda:0").eval()
+        net.fuse_next_q = on
+        outs[on] = net.forward_batch([dev(src)], [dev(tgt)])[0].cpu()
+        mt, (layers, _), _keep = net._pack_weights()
+        assert [int(L.tail_next_q) for L in layers] == ([0, 0, 1, 0, 1, 0] if on else [0] * 6)
+    torch.testing.assert_close(outs[True], outs[False], rtol=2e-5, atol=2e-6)
+
+
 def test_tail_two_stream_soak_short():
     """tools/tail_soak.py for ~15 s: random row counts / cloud partitions of the fused layer tail on two streams at once
     (the lanes configuration), each draw against the unfused chain and twice for bitwise repeatability (the long runs are

@@ -46,8 +46,9 @@ def test_host_side_argument_checks_need_no_gpu():
     # six cross layers' target-side K^T V partials (one 128-row target tile x 8 heads x 1056 floats) and images side by side
     assert lib.scream_forward_workspace_bytes(128, 256, 1, 1, 1, 6) - fused == 6 * (8 * 1056 * 4 + lib.scream_kv_image_bytes())
     # the split entry points validate `split` and the fp16 exponents on the host
-    assert [lib.scream_tail_image_bytes(k) for k in (1, 2, 3)] == [72 * 16 * 1024, 72 * 32 * 1024, 72 * 48 * 1024]
-    assert lib.scream_tail_image_bytes(4) == -1
+    assert [lib.scream_tail_image_bytes(k, 0) for k in (1, 2, 3)] == [72 * 16 * 1024, 72 * 32 * 1024, 72 * 48 * 1024]
+    assert [lib.scream_tail_image_bytes(k, 1) for k in (1, 2, 3)] == [80 * 16 * 1024, 80 * 32 * 1024, -1]  # the next layer's query stages: fp16 splits
+    assert lib.scream_tail_image_bytes(4, 0) == -1
     # NULL pointers / bad shapes are rejected before any launch
     assert lib.scream_gemm_f32(None, 256, None, None, 256, 128, 256, 256, 0, 0, None, None, 0, None, None, None) == -1
     assert lib.scream_nn_search(*([None] * 7), 1, 1, 1, 128, 128, 0.1, *([None] * 6)) == -1
@@ -398,7 +399,7 @@ def test_no_instruction_touches_a_register_whose_asm_load_is_pending(tmp_path):
                 assert not any(re.match(r"\s*scratch_", l) for l in body), "scratch traffic in " + want
                 drains = sum(1 for l in body if re.match(r"\s*s_waitcnt vmcnt\(0\)", l))
                 assert drains <= 8, drains
-        assert n_kernels == {"gemm_split.hip": 36, "tail_split.hip": 3}[src]  # every operand split of each
+        assert n_kernels == {"gemm_split.hip": 36, "tail_split.hip": 5}[src]  # every operand split of each (the tail: + the two fp16 splits with the next layer's query stages)
 
 
 def test_the_static_checker_detects_what_it_is_there_for():
@@ -476,7 +477,7 @@ def test_tuning_builds_are_verified_before_they_can_be_launched(tmp_path):
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import asm_inflight_check as chk
     src = os.path.join(REPO, "scream_amd", "csrc", "tail_split.hip")
-    assert chk.verify_source(src, ["-ffp-contract=off", "-DT_ABLATE=1"], str(tmp_path / "t1.s"), "11tail_kernelINS_7SplitH2") == 1
+    assert chk.verify_source(src, ["-ffp-contract=off", "-DT_ABLATE=1"], str(tmp_path / "t1.s"), "11tail_kernelINS_7SplitH2") == 2  # (with and without the next layer's query stages)
     bad = tmp_path / "bad.hip"  # a register load consumed behind a wait that does not cover it
     bad.write_text("""#include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));

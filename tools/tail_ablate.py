@@ -25,7 +25,7 @@ def build():
         flags = ["-ffp-contract=off", "-DT_ABLATE=%d" % bits, *EXTRA]
         want = "11tail_kernelINS_" + {"h2": "7SplitH2", "x3": "8SplitBf3"}[os.environ.get("T_SPLIT", "h2")]  # the instance `run` will launch
         try:
-            assert chk.verify_source(SRC, flags, os.path.join(OUT, "t_%d.s" % bits), want) == 1
+            assert chk.verify_source(SRC, flags, os.path.join(OUT, "t_%d.s" % bits), want) >= 1
         except RuntimeError as e:  # never launch a variant whose generated code touches a pending register: skip it, loudly
             print("SKIPPED variant %d (%s): %s" % (bits, label, e), flush=True)
             if os.path.exists(os.path.join(OUT, "t_%d.so" % bits)): os.remove(os.path.join(OUT, "t_%d.so" % bits))
@@ -93,17 +93,17 @@ def run():
             if not os.path.exists(f): continue
             lib = ctypes.CDLL(f)
             ft = lib.scream_layer_tail_f32; ft.restype = ctypes.c_int
-            ft.argtypes = [V, V, V, I32, V, V, V, V, V, V, V, V, I64, I32, ctypes.POINTER(_lib.TailExpsT), V]
-            pt = lib.scream_pack_tail; pt.restype = ctypes.c_int; pt.argtypes = [V, V, V, I32, ctypes.POINTER(_lib.TailExpsT), V, V]
+            ft.argtypes = [V, V, V, I32, V, V, V, V, V, V, V, V, V, I64, I32, ctypes.POINTER(_lib.TailExpsT), V]
+            pt = lib.scream_pack_tail; pt.restype = ctypes.c_int; pt.argtypes = [V, V, V, V, I32, ctypes.POINTER(_lib.TailExpsT), V, V]
             kf = lib.scream_kv_finalize_x3; kf.restype = ctypes.c_int; kf.argtypes = [V, V, V, I64, I32, I32, V, I32, I64, I64, V]
-            tb = lib.scream_tail_image_bytes; tb.restype = ctypes.c_int64; tb.argtypes = [I32]
-            timg = torch.empty(tb(split), device=dev, dtype=torch.uint8)
-            assert pt(Wm.data_ptr(), W1.data_ptr(), W2.data_ptr(), split, ctypes.byref(EX), timg.data_ptr(), st) == 0
+            tb = lib.scream_tail_image_bytes; tb.restype = ctypes.c_int64; tb.argtypes = [I32, I32]
+            timg = torch.empty(tb(split, 0), device=dev, dtype=torch.uint8)
+            assert pt(Wm.data_ptr(), W1.data_ptr(), W2.data_ptr(), None, split, ctypes.byref(EX), timg.data_ptr(), st) == 0
             kvi = torch.zeros(n_clouds, lib.scream_kv_image_bytes(), device=dev, dtype=torch.uint8)
             assert kf(part.data_ptr(), crow0.data_ptr(), clen.data_ptr(), 0, 0, n_clouds, kvi.data_ptr(), 1, 0, 0, st) == 0
             calls.append(((tag + " " if tag else "") + "fused tail: " + label,
                           (lambda ft=ft, timg=timg, kvi=kvi: ft(Qf.data_ptr(), kvi.data_ptr(), tile_cloud.data_ptr(), 0, clen.data_ptr(), xf.data_ptr(),
-                                                                timg.data_ptr(), gam.data_ptr(), bet.data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(), M,
+                                                                timg.data_ptr(), gam.data_ptr(), bet.data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(), None, M,
                                                                 split, ctypes.byref(EX), st))))
     print("%-50s %9s %9s %9s %10s %9s  (M=%d, split %s; merge + FFN = %.1f GFLOP)" % ("variant", "ms", "sclk MHz", "power W", "J/launch", "TFLOP/s", M, os.environ.get("T_SPLIT", "h2"), 2.0 * M * 256 * 2304 / 1e9))
     for label, call in calls:

@@ -19,6 +19,11 @@ Wv = torch.cat([Wqkv[384:512], Wqkv[640:768]])  # the value rows of [q | k0-3 | 
 EX = ops.tail_exps(**scales.tail_exps(Wm, W1, W2, g1, b1, XMAX * float(Wv.abs().sum(dim=1).max())))
 P = {sp: dict(q=ops.pack_w(Wqkv, sp), m=ops.pack_w(Wm, sp), w1=ops.pack_w(W1, sp), w2=ops.pack_w(W2, sp), img=ops.pack_tail(Wm, W1, W2, sp, EX))
      for sp in (ops.SPLIT_H2, ops.SPLIT_BF3)}
+# a third of the draws: the fp16 kernel with the NEXT layer's query projection behind norm2 (eight more ring stages, Q' written in place)
+Wqn = torch.randn(256, 256, device=dev, generator=g) / 16
+E_Y, E_WQ = scales.exp_for(scales.ln_bound(g2, b2)), scales.w_exp(Wqn)
+EXQ = ops.tail_exps(e_y=E_Y, e_wq=E_WQ, **scales.tail_exps(Wm, W1, W2, g1, b1, XMAX * float(Wv.abs().sum(dim=1).max())))
+IMG_Q, PQN = ops.pack_tail(Wm, W1, W2, ops.SPLIT_H2, EXQ, Wq_next=Wqn), ops.pack_w(Wqn, ops.SPLIT_H2, E_WQ)
 FR = ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG
 torch.cuda.synchronize()
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
@@ -38,12 +43,19 @@ while time.time() - t0 < secs:
             tc, cr, cl = torch.from_numpy(tiles).to(dev), torch.from_numpy(row0).to(dev), torch.from_numpy(lens).to(dev)
             x = torch.randn(M, 256, device=dev).clamp_(-XMAX, XMAX)
             xf = ops.act_layout(x, True)
-            p = P[(ops.SPLIT_H2, ops.SPLIT_BF3)[rng.integers(2)]]
+            kind = int(rng.integers(3))
+            p = P[(ops.SPLIT_H2, ops.SPLIT_BF3, ops.SPLIT_H2)[kind]]
             img = p["img"]
             Qf, part = ops.gemm_qkv(xf, p["q"], 256, tc, cr, cl, 0, FR, a_exp=A_EXP)
             kvi = ops.kv_finalize_x3(part, cr, cl, 0, 0, n_clouds, n_clouds)
-            y1 = ops.layer_tail(Qf, kvi, tc, 0, cl, xf, img, g1, b1, g2, b2)
-            y2 = ops.layer_tail(Qf, kvi, tc, 0, cl, xf, img, g1, b1, g2, b2)
+            if kind == 2:
+                qa, qb = Qf.clone(), Qf.clone()
+                y1 = ops.layer_tail(qa, kvi, tc, 0, cl, xf, IMG_Q, g1, b1, g2, b2, q_next=qa)
+                y2 = ops.layer_tail(qb, kvi, tc, 0, cl, xf, IMG_Q, g1, b1, g2, b2, q_next=qb)
+                qref = ops.gemm_split(y1, PQN, ops.EPI_ELU1, n_act=256, layout=FR, a_exp=E_Y)
+            else:
+                y1 = ops.layer_tail(Qf, kvi, tc, 0, cl, xf, img, g1, b1, g2, b2)
+                y2 = ops.layer_tail(Qf, kvi, tc, 0, cl, xf, img, g1, b1, g2, b2)
             kv = ops.kv_finalize(part, cr, cl, 0, 0, n_clouds, n_clouds)
             att = ops.attn_apply(ops.act_layout(Qf, False), 256, kv, tc, 0, cl, M)
             m1 = ops.gemm_split(att, p["m"], ops.EPI_RES_LN, residual=x, gamma=g1, beta=b1, a_exp=EX.e_att)
@@ -55,6 +67,9 @@ while time.time() - t0 < secs:
                 valid[r0:r0 + ln] = True
             err = ((yr - ref).abs() * valid[:, None]).max()
             same = torch.equal(y1, y2)
+            if kind == 2:  # the projected queries: against the projection GEMM of the same y, and repeatable
+                err = torch.maximum(err, ((ops.act_layout(qa, False) - ops.act_layout(qref, False)).abs() * valid[:, None]).max() * 100)  # (tolerance 1e-5)
+                same = same and torch.equal(qa, qb)
             jobs.append((M, n_clouds, err, same))
     torch.cuda.synchronize()
     if n % 100 == 0: print("progress", n, "%.0f s" % (time.time() - t0), flush=True)

@@ -14,7 +14,7 @@ def build():
     src = os.path.join(ROOT, "scream_amd/csrc/tail_split.hip")
     flags = ["-ffp-contract=off", "-DT_STAMPS", *os.environ.get("T_EXTRA", "").split()]
     want = "11tail_kernelINS_" + {"h2": "7SplitH2", "x3": "8SplitBf3"}[os.environ.get("T_SPLIT", "h2")]  # the instance `run` launches
-    assert chk.verify_source(src, flags, SO[:-3] + ".s", want) == 1  # raises if a stamp pushed a pending register around
+    assert chk.verify_source(src, flags, SO[:-3] + ".s", want) >= 1  # raises if a stamp pushed a pending register around
     subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", *flags, src, "-o", SO])
 
 
@@ -42,18 +42,18 @@ def run():
     lib = ctypes.CDLL(SO)
     V, I64, I32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
     ft = lib.scream_layer_tail_f32; ft.restype = ctypes.c_int
-    ft.argtypes = [V, V, V, I32, V, V, V, V, V, V, V, V, I64, I32, ctypes.POINTER(_lib.TailExpsT), V]
-    pt = lib.scream_pack_tail; pt.restype = ctypes.c_int; pt.argtypes = [V, V, V, I32, ctypes.POINTER(_lib.TailExpsT), V, V]
+    ft.argtypes = [V, V, V, I32, V, V, V, V, V, V, V, V, V, I64, I32, ctypes.POINTER(_lib.TailExpsT), V]
+    pt = lib.scream_pack_tail; pt.restype = ctypes.c_int; pt.argtypes = [V, V, V, V, I32, ctypes.POINTER(_lib.TailExpsT), V, V]
     kf = lib.scream_kv_finalize_x3; kf.restype = ctypes.c_int; kf.argtypes = [V, V, V, I64, I32, I32, V, I32, I64, I64, V]
-    tb = lib.scream_tail_image_bytes; tb.restype = ctypes.c_int64; tb.argtypes = [I32]
+    tb = lib.scream_tail_image_bytes; tb.restype = ctypes.c_int64; tb.argtypes = [I32, I32]
     st = torch.cuda.current_stream().cuda_stream
-    timg = torch.empty(tb(split), device=dev, dtype=torch.uint8)
-    assert pt(Wm.data_ptr(), W1.data_ptr(), W2.data_ptr(), split, ctypes.byref(EX), timg.data_ptr(), st) == 0
+    timg = torch.empty(tb(split, 0), device=dev, dtype=torch.uint8)
+    assert pt(Wm.data_ptr(), W1.data_ptr(), W2.data_ptr(), None, split, ctypes.byref(EX), timg.data_ptr(), st) == 0
     kvi = torch.zeros(n_clouds, lib.scream_kv_image_bytes(), device=dev, dtype=torch.uint8)
     assert kf(part.data_ptr(), crow0.data_ptr(), clen.data_ptr(), 0, 0, n_clouds, kvi.data_ptr(), 1, 0, 0, st) == 0
     y = torch.empty(M, 256, device=dev)
     call = lambda: ft(Qf.data_ptr(), kvi.data_ptr(), tile_cloud.data_ptr(), 0, clen.data_ptr(), xf.data_ptr(), timg.data_ptr(), gam.data_ptr(),
-                      bet.data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(), M, split, ctypes.byref(EX), st)
+                      bet.data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(), None, M, split, ctypes.byref(EX), st)
     import time
     t0 = time.time()
     while time.time() - t0 < 1.5:
