@@ -146,7 +146,11 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
     constexpr int NP = SP::NP;
     constexpr int STAGE = stage_bytes<SP>();
     constexpr int PIECES = wave_pieces<SP>();  // LDS-DMA pieces per wave and stage = what a counted ring wait leaves in flight
+#ifdef T_NV_MERGE  // tuning aid (tools/tail_stamps.py, T_EXTRA): another ride-slot count
+    constexpr int NV_MERGE = T_NV_MERGE;
+#else
     constexpr int NV_MERGE = SP::NPROD >= 6 ? 6 : 8;  // ride slots behind every MFMA of a merge stage (32 cycles / 4 per VALU issue)
+#endif
     // The last ND MFMA groups of every stage are DEFERRED across the barrier (below): 192 cycles of work on register operands
     // must cover the barrier skew and the first fragment reads of the next stage -- one group of six bf16 products, two groups
     // of three fp16 products.
