@@ -508,11 +508,18 @@ def main():
     trec, tpath = load_traffic_record()
     traffic = None
     if trec is not None:
-        dom = next((v for k_, v in trec["kernels"].items() if ("tail_kernel" if fused else "gemm") in k_), None)
+        # the dominant kernel's bytes per launch: every instantiation of it pooled (the layer tail has two since round 3: with and
+        # without the next layer's query stages) -- bytes per step over launches per step
+        dom_k = [v for k_, v in trec["kernels"].items() if k_.startswith("tail_kernel" if fused else "gemm")]
+        dom = None
+        if dom_k:
+            n_launch = sum(v["dispatches_fetch_pass"] for v in dom_k) / max(trec.get("steps_in_fetch_pass", 1.0), 1e-9)
+            dom = {"fetch_bytes_per_launch": sum(v["fetch_bytes_per_step"] for v in dom_k) / n_launch,
+                   "write_bytes_per_launch": sum(v["write_bytes_per_step"] for v in dom_k) / n_launch}
         per_launch_algo = None
         if fused:  # the layer-tail kernel by itself: Q' + y per token and application (x is re-read from the projection's pass).
             # Per launch AT THE LANE COUNT OF THE COUNTER RECORD (a launch covers 1 / lanes of the step's rows): like for like
-            per_launch_algo = 2048.0 * sum(6 * (n + m) + 12 * n for n, m in zip(src_len, tgt_len)) / (18.0 * trec.get("lanes", 1))
+            per_launch_algo = (2048.0 * sum(6 * (n + m) + 12 * n for n, m in zip(src_len, tgt_len)) + (1024.0 * 6 * sum(src_len) if net.fuse_next_q and gb != "x3" else 0.0)) / (18.0 * trec.get("lanes", 1))  # (+ Q' of the next layer where the tail writes it)
         traffic = {"counter_bytes_per_step": round(trec["hbm_bytes_per_step"] * B / PAIRS_PER_GPU),
                    "algorithmic_bytes_per_step": round(algo_b + weight_b), "design_bytes_per_step": round(design_b + weight_b),
                    "ratio": round(trec["hbm_bytes_per_step"] * B / PAIRS_PER_GPU / (algo_b + weight_b), 3),
