@@ -251,6 +251,32 @@ def test_evaluate_loader_with_gpu_icp_only_improves():
     assert (ref[:, sdist.COL_TE] < base[:, sdist.COL_TE]).any()  # the accept rule fires on at least one pair
 
 
+def test_batches_in_flight_do_not_change_results():
+    """evaluate_loader(in_flight=n) / evaluate_kitti.evaluate(in_flight=n): n batches enqueued on n streams, each with its own
+    staging buffers and workspace (round 3).  Pairs never interact, every batch runs the same kernels on the same inputs: the
+    metric tuple is identical, bit for bit, for 1 (KITTI), 2, 3 and 4 batches in flight, with the GPU ICP on."""
+    from scream_amd.evaluate import evaluate_loader
+    from scream_amd.evaluate_kitti import SyntheticKittiPairs, evaluate
+    from scream_amd.model import PointTransformer
+    net = PointTransformer(256, 1, 1)
+    net.load_state_dict(make_state_dict(5, 256, 1, 1))
+    net = net.to(DEV).eval()
+    ds = SyntheticPairs("3dmatch", 11, seed0=60)
+    items = [ds[i] for i in range(len(ds))]
+
+    def hook(batch, src_pred, ids):  # realistic correspondences, so that the ICP has work to do
+        out = src_pred.clone()
+        for k, i in enumerate(ids):
+            r0 = int(batch.cloud_row0_host[k])
+            out[r0:r0 + items[i][0].shape[0]] = _noisy_registered(items[i], i).to(DEV)
+        return out
+    outs = [evaluate_loader(net, ds, batch_pairs=2, icp="gpu", verbose=False, pred_hook=hook, in_flight=n) for n in (2, 3, 4)]
+    assert outs[0] == outs[1] == outs[2], outs
+    kd = SyntheticKittiPairs(5)
+    kouts = [evaluate(net, kd, batch_pairs=2, skip=(), verbose=False, icp_iters=40, in_flight=n) for n in (1, 4)]
+    assert kouts[0] == kouts[1], kouts
+
+
 def test_kitti_harness_large_clouds():
     """BASELINE config 4 size (voxel 0.7, ~13-16k points per cloud): the KITTI loop with bbox normalisation,
     dis_thresh 1.5, src_center = -(R^T t)^T, GPU ICP (radius 1 m, early exit), success = RE <= 5 and TE <= 2."""
