@@ -88,7 +88,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[8], float* slabs, in
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         float a = acc[hq][e];
-                        a = a > 0.f ? a + 1.0f : expf(a);                  // elu(k) + 1
+                        a = elu1(a);                                       // elu(k) + 1
                         if (mfma32_row(e, half) >= valid_w) a = 0.f;       // padding rows do not exist
                         ks += a;
                         SplitH2::split1(a * ep.kv_sk, e & 7, kp[e >> 3]);
@@ -101,7 +101,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[8], float* slabs, in
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         float a = acc[hq][e];
-                        a = a > 0.f ? a + 1.0f : expf(a);                  // elu(k) + 1
+                        a = elu1(a);                                       // elu(k) + 1
                         if (mfma32_row(e, half) >= valid_w) a = 0.f;       // padding rows do not exist
                         kv = __builtin_amdgcn_mfma_f32_32x32x2f32(a, acc[4 + hq][e], kv, 0, 0, 0);  // (1 / v_length is applied once, in scream_kv_finalize)
                         ks += a;
@@ -150,7 +150,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[8], float* slabs, in
             for (int blk = 0; blk < 8; ++blk) {
                 f32x4 v = ld4(slab + rr * 256 + (((8 * blk + 2 * a + hf) ^ rr) << 2));
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] + 1.0f : expf(v[c]);  // elu(x)+1 == exp(x), x <= 0
+                for (int c = 0; c < 4; ++c) v[c] = elu1(v[c]);
                 *reinterpret_cast<f32x4*>(cg + ((blk * 4 + a) * 64 + 8 * g + rr + 32 * hf) * 4) = v;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -213,7 +213,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[8], float* slabs, in
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) vv[i][c] = vv[i][c] > 0.f ? vv[i][c] + 1.0f : expf(vv[i][c]);  // elu(x)+1 == exp(x), x <= 0
+                        for (int c = 0; c < 4; ++c) vv[i][c] = elu1(vv[i][c]);
                 }
             } else if (EPI == SCREAM_EPI_RELU) {
 #pragma unroll

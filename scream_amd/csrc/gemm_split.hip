@@ -353,7 +353,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_split_kernel(const float* __
 #pragma unroll
                             for (int b = 0; b < 4; ++b) {
                                 const float x = acc[tn][4 * a + b];
-                                o[b] = x > 0.f ? x + 1.0f : expf(x);  // elu(x) + 1 == exp(x), x <= 0
+                                o[b] = elu1(x);
                             }
                             *reinterpret_cast<f32x4*>(cg + (tn * 4 + a) * 256) = o;
                         }

@@ -675,7 +675,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
                 for (int e = 0; e < 2; ++e) {
                     const int i = 2 * k + e;
                     const float x = h[i] * sc.cq;
-                    oq[i >> 2][i & 3] = x > 0.f ? x + 1.0f : expf(x);  // elu(x) + 1 == exp(x), x <= 0
+                    oq[i >> 2][i & 3] = elu1(x);
                 }
             };
             auto store_chunk = [&](int j) {

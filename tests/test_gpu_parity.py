@@ -188,6 +188,23 @@ def test_gemm_rejects_bad_shapes():
         ops.gemm_f32(torch.zeros(128, 256), torch.zeros(256, 256))  # CPU tensors: no fallback
 
 
+def test_elu_feature_map_is_within_two_ulp_of_float64():
+    """elu(x) + 1 of every epilogue (csrc/common.h:elu1: exp2 on the hardware with a first-order correction of the argument's
+    rounding) against float64, through the fp32-input GEMM with an identity weight (its products and sums are exact there)."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.cat([torch.rand(128, 256, generator=g) * 100 - 95, torch.randn(128, 256, generator=g) * 3,
+                   torch.tensor([0.0, -0.0, -1e-30, -87.0, -103.0, -200.0, 1e-30, 88.0, 3e38]).repeat(256 * 128 // 9 + 1)[:256 * 128].reshape(128, 256)])
+    got = ops.gemm_f32(dev(x), dev(torch.eye(256)), ops.EPI_ELU1, n_act=256).cpu().double()
+    xd = x.double()
+    want = torch.where(xd > 0, xd + 1.0, torch.exp(xd))
+    # (v_exp_f32 flushes results below the smallest normal number to zero, the reference's exp returns them as denormals: 1e-38 of
+    # a feature whose useful range starts nine orders of magnitude higher)
+    ulp = torch.maximum(want.abs(), torch.tensor(2.0 ** -126, dtype=torch.float64)) * 2.0 ** -23
+    assert torch.isfinite(got).all()
+    err = ((got - want).abs() - 2.0 ** -126).clamp(min=0) / ulp
+    assert float(err.max()) <= 2.0, float(err.max())
+
+
 # ------------------------------------------------------------------------------ A1 embedding
 def test_pe_embed_prenorm_vs_oracle(golden):
     from scream_amd.model import pe_dim_t
