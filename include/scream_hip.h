@@ -349,6 +349,12 @@ int scream_rigid_transform_3d(const float* A, const float* B, const float* w,
 int scream_transformation_error(const float* T_pred, const float* T_gt, int32_t n, float* re,
                                 float* te, void* stream);
 
+/* ---- A11 (the per-pair L1 point loss the evaluators report): loss[p] = mean_n sum_xyz |src_pred_n - (R_p src_n + t_p)|
+ * Replaces PointTransformer.loss (models/pointnet.py:93-99) called once per pair (evaluate_3d_match.py:86): src_pred / src packed
+ * [rows,3] in the normalised frame, rot [n_pairs,9] / trans [n_pairs,3] the ground-truth pose of the same frame. */
+int scream_point_loss(const float* src_pred, const float* src, const int32_t* src_row0, const int32_t* src_len,
+                      const float* rot, const float* trans, int32_t n_pairs, float* loss, void* stream);
+
 /* ---- next row: batched point-to-point ICP refinement on the GPU.
  * Replaces o3d.registration_icp(src_pc, tgt_pc, max_correspondence_distance, init) at
  * evaluate_3d_match.py:106-113 / evaluate_kitti.py:61-70 (open3d is absent here: parity with open3d is

@@ -337,6 +337,33 @@ __global__ __launch_bounds__(64) void transformation_error_kernel(const float* _
 // the search and solve kernels; all pairs of a batch iterate together and converged pairs freeze on the
 // device (no host synchronisation inside the loop).
 
+// loss[p] = mean_n sum_xyz |pred_n - (R_p a_n + t_p)| (models/pointnet.py:93-99, the L1 point loss the evaluators report per pair).
+// One workgroup per pair; the terms in fp32 like the reference's, their sum in fp64 in a fixed order (the torch expression costs
+// seven small launches per pair).
+__global__ __launch_bounds__(256) void point_loss_kernel(const float* __restrict__ pred, const float* __restrict__ src,
+                                                        const int32_t* __restrict__ row0, const int32_t* __restrict__ len,
+                                                        const float* __restrict__ R, const float* __restrict__ t,
+                                                        float* __restrict__ out) {
+    __shared__ double red[4];
+    const int p = blockIdx.x, n = len[p];
+    const int64_t r0 = row0[p];
+    const float* Rp = R + p * 9;
+    const float* tp = t + p * 3;
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float x = src[(r0 + i) * 3 + 0], y = src[(r0 + i) * 3 + 1], z = src[(r0 + i) * 3 + 2];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float reg = ((Rp[k * 3 + 0] * x + Rp[k * 3 + 1] * y) + Rp[k * 3 + 2] * z) + tp[k];
+            s += fabsf(pred[(r0 + i) * 3 + k] - reg);
+        }
+        acc[0] += (double)s;
+    }
+    block_sum<1, 256>(acc, red);
+    if (threadIdx.x == 0) out[p] = n > 0 ? (float)(acc[0] / n) : 0.f;
+}
+
 // metric frame: x / s + c (evaluate_3d_match.py:106-107)
 __global__ __launch_bounds__(256) void icp_to_metric_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ row0,
                                                            const int32_t* __restrict__ len, const float* __restrict__ s,
@@ -612,6 +639,15 @@ extern "C" int scream_rigid_transform_3d(const float* A, const float* B, const f
     SCREAM_REQUIRE(K == 0 || (A && B), SCREAM_EINVAL);
     if (bs == 0) return 0;
     kabsch_dense_kernel<<<dim3(bs), dim3(256), 0, as_stream(stream)>>>(A, B, w, weight_threshold, K, T_out);
+    SCREAM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int scream_point_loss(const float* src_pred, const float* src, const int32_t* src_row0, const int32_t* src_len,
+                                 const float* rot, const float* trans, int32_t n_pairs, float* loss, void* stream) {
+    SCREAM_REQUIRE(src_pred && src && src_row0 && src_len && rot && trans && loss && n_pairs >= 0, SCREAM_EINVAL);
+    if (n_pairs == 0) return 0;
+    point_loss_kernel<<<dim3(n_pairs), dim3(256), 0, as_stream(stream)>>>(src_pred, src, src_row0, src_len, rot, trans, loss);
     SCREAM_LAUNCH_CHECK();
     return 0;
 }

@@ -145,9 +145,8 @@ def _register_lane(net, its, centers, pair_ids, corr, dis_thresh, icp, icp_dist,
         better = (re2 <= re) & (te2 <= te)
         T = torch.where(better[:, None, None], T2, T)
         re, te = torch.where(better, re2, re), torch.where(better, te2, te)
-    preds = batch.unpack_src(src_pred)
-    srcs = batch.unpack_src(batch.xyz[: batch.rows_src])
-    loss = torch.stack([net.loss(preds[i][None], srcs[i][None], rot_d[i:i + 1], trans_d[i:i + 1]) for i in range(B)])
+    # PointTransformer.loss per pair (models/pointnet.py:93-99, evaluate_3d_match.py:86) for the whole batch in one launch
+    loss = ops.point_loss(src_pred.contiguous(), batch.xyz[: batch.rows_src], batch.src_row0, batch.src_len_dev, rot_d, trans_d)
     return T, T_gt, T_gt_d, re, te, loss
 
 

@@ -329,6 +329,17 @@ def transformation_error_batched(T_pred: torch.Tensor, T_gt: torch.Tensor) -> Tu
     return re, te
 
 
+def point_loss(src_pred: torch.Tensor, src: torch.Tensor, src_row0, src_len, rot: torch.Tensor, trans: torch.Tensor) -> torch.Tensor:
+    """models/pointnet.py:93-99 per pair of a packed batch: loss[p] = mean_n sum_xyz |src_pred_n - (rot_p src_n + trans_p)|.
+    src_pred / src packed [rows,3]; rot [B,3,3]; trans [B,3,1] or [B,3]."""
+    B = rot.shape[0]
+    out = torch.empty(B, device=src_pred.device, dtype=torch.float32)
+    check(_lib.load().scream_point_loss(_p(src_pred), _p(src), _p(src_row0, torch.int32), _p(src_len, torch.int32),
+                                        _p(rot.reshape(B, 9).contiguous()), _p(trans.reshape(B, 3).contiguous()), B, _p(out), _stream()),
+          "scream_point_loss")
+    return out
+
+
 def icp_p2p(src, ref, src_row0, src_len, ref_row0, ref_len, s, c, T_init, max_src_len: int, max_ref_len: int,
             max_corr_dist: float, max_iter: int = 30, rel_fitness: float = 1e-6, rel_rmse: float = 1e-6):
     """Batched point-to-point ICP (scream_icp_p2p).  Returns (T [n,4,4], fitness_rmse [n,2], iters int32 [n])."""

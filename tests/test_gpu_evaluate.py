@@ -8,6 +8,7 @@ import torch
 
 from oracle import scream_ref as O
 from scream_amd import dist as sdist
+from scream_amd import ops
 from scream_amd.data import SyntheticPairs
 from scream_amd.synthetic import make_state_dict
 
@@ -249,6 +250,27 @@ def test_evaluate_loader_with_gpu_icp_only_improves():
     assert (ref[:, sdist.COL_RE] <= base[:, sdist.COL_RE] + 1e-6).all()
     assert (ref[:, sdist.COL_TE] <= base[:, sdist.COL_TE] + 1e-9).all()
     assert (ref[:, sdist.COL_TE] < base[:, sdist.COL_TE]).any()  # the accept rule fires on at least one pair
+
+
+def test_point_loss_kernel_vs_the_reference_expression():
+    """scream_point_loss (one launch per batch) against PointTransformer.loss = models/pointnet.py:93-99 per pair (seven small
+    launches each), ragged clouds."""
+    from scream_amd.model import PointTransformer
+    from scream_amd.packing import PackedBatch
+    g_ = torch.Generator().manual_seed(9)
+    lens = [300, 1, 2, 4097, 777]
+    srcs = [torch.rand(n, 3, generator=g_) - 0.5 for n in lens]
+    tgts = [torch.rand(5, 3, generator=g_) for _ in lens]
+    batch = PackedBatch.from_pairs([s.to(DEV) for s in srcs], [t.to(DEV) for t in tgts], [None] * len(lens))
+    pred = torch.randn(batch.rows_src, 3, generator=g_).to(DEV)
+    rot = torch.linalg.qr(torch.randn(len(lens), 3, 3, generator=g_))[0].contiguous()
+    trans = torch.randn(len(lens), 3, 1, generator=g_)
+    got = ops.point_loss(pred, batch.xyz[: batch.rows_src], batch.src_row0, batch.src_len_dev, rot.to(DEV), trans.to(DEV)).cpu()
+    net = PointTransformer(256, 1, 1)
+    preds = batch.unpack_src(pred.cpu())
+    for i, n in enumerate(lens):
+        want = net.loss(preds[i][None], srcs[i][None], rot[i:i + 1], trans[i:i + 1])
+        torch.testing.assert_close(got[i], want, rtol=2e-6, atol=1e-7)
 
 
 def test_batches_in_flight_do_not_change_results():
