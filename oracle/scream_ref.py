@@ -102,23 +102,33 @@ def layer_counts(sd: Dict[str, torch.Tensor]) -> Tuple[int, int]:
 
 
 def point_transformer_forward(src: torch.Tensor, tgt: torch.Tensor, sd: Dict[str, torch.Tensor],
-                              src_center: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """models/pointnet.py:38-60: returns src_ [1,N,3] (predicted registered src coordinates)."""
+                              src_center: Optional[torch.Tensor] = None, wants: Optional[list] = None) -> torch.Tensor:
+    """models/pointnet.py:38-60: returns src_ [1,N,3] (predicted registered src coordinates).
+    wants: a list that receives (prefix, side, intermediates of mh_attention) per block application, for tests that look at
+    the operand ranges inside the network."""
     assert src.shape[0] == 1 and tgt.shape[0] == 1
     n_self, n_cross = layer_counts(sd)
     if src_center is None:
         src_center = torch.mean(src, dim=1, keepdim=True)  # pointnet.py:43-44
     sf = embed_prenorm(src, src - src_center, sd)
     tf = embed_prenorm(tgt, tgt, sd)
+    def block(xq, xkv, p, side):
+        w = {} if wants is not None else None
+        out = mh_attention(xq, xkv, xkv, sd, p, w)
+        if wants is not None:
+            w.update(xq=xq, xkv=xkv)
+            wants.append((p, side, w))
+        return out
+
     for i in range(n_self):  # pointnet.py:50-52 -- shared weights, tgt first
         p = "stem.%d." % i
-        tf = mh_attention(tf, tf, tf, sd, p)
-        sf = mh_attention(sf, sf, sf, sd, p)
+        tf = block(tf, tf, p, "tgt")
+        sf = block(sf, sf, p, "src")
     for i in range(2 * n_cross):  # pointnet.py:53-57
         if i % 2 == 0:
-            sf = mh_attention(sf, sf, sf, sd, "cross.%d." % i)
+            sf = block(sf, sf, "cross.%d." % i, "src")
         else:
-            sf = mh_attention(sf, tf, tf, sd, "cross.%d.layer." % i)
+            sf = block(sf, tf, "cross.%d.layer." % i, "src")
     # coor_mlp, pointnet.py:27-33,60 (Conv1d k=1 == per-point Linear with bias)
     h = torch.relu(sf @ sd["coor_mlp.0.weight"][:, :, 0].t() + sd["coor_mlp.0.bias"])
     h = torch.relu(h @ sd["coor_mlp.2.weight"][:, :, 0].t() + sd["coor_mlp.2.bias"])

@@ -47,7 +47,8 @@
 // starves the LDS and vector-memory instructions of the other wave on its SIMD (not its VALU), which is why the
 // k-tile time is close to the SUM of the MFMA, LDS, VMEM and VALU issue times rather than their maximum.
 // Tuning aid (tools/x3_ablate.py builds variants): bit 0 no epilogue, 1 no W DMA after the first k-tile, 2 no A loads
-// after the first, 3 no MFMAs, 4 no LDS fragment reads, 5 no operand split.  Always 0 in libscream_hip.so.
+// after the first, 3 no MFMAs, 4 no LDS fragment reads, 5 no operand split, 6 no epilogue stores, 7 no key/value-tile epilogue
+// (the fused K^T V reduce), 8 no query-tile epilogue (elu + 1 and the fragment-major stores).  Always 0 in libscream_hip.so.
 #ifndef X3_ABLATE
 #define X3_ABLATE 0
 #endif
@@ -325,7 +326,9 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_split_kernel(const float* __
             ga = a_ptr(m0, rows_ok);
         }
         if (has_next) request_first();
-        if (X3_ABLATE & 1) {
+        const bool skip_epi = (X3_ABLATE & 1) || ((X3_ABLATE & 128) && EPI == SCREAM_EPI_QKV && n0_cur >= ep.n_act) ||
+                              ((X3_ABLATE & 256) && CAN_TR && tr_cur);
+        if (skip_epi) {
             float keep = 0.f;
 #pragma unroll
             for (int tn = 0; tn < 8; ++tn)

@@ -109,7 +109,7 @@ _staging = {}  # (device, lane stream) -> StagingBuffers
 IN_FLIGHT = int(os.environ.get("SCREAM_IN_FLIGHT", "4"))
 
 
-def _register_lane(net, its, centers, pair_ids, corr, dis_thresh, icp, icp_dist, icp_iters, device, pred_hook):
+def _register_lane(net, its, centers, pair_ids, corr, dis_thresh, icp, icp_dist, icp_iters, device, pred_hook, backend=None):
     """Device part of register_items for one lane (runs on the current stream): pack, A1-A6, A7-A9, A10 (+ GPU ICP).
     Nothing here blocks the host: the batch and every per-pair scalar go up in two asynchronous copies from pinned
     memory (a pageable copy or a torch.tensor(..., device=) would wait for everything already queued on the stream)."""
@@ -127,7 +127,7 @@ def _register_lane(net, its, centers, pair_ids, corr, dis_thresh, icp, icp_dist,
     s, c = ex[:B], ex[B:4 * B].view(B, 3)
     T_gt_d = ex[4 * B:20 * B].view(B, 4, 4)
     rot_d, trans_d = ex[20 * B:29 * B].view(B, 3, 3), ex[29 * B:32 * B].view(B, 3, 1)
-    src_pred = net.forward_packed(batch)
+    src_pred = net.forward_packed(batch) if backend is None else net.forward_packed(batch, backend=backend)
     if pred_hook is not None:
         src_pred = pred_hook(batch, src_pred, pair_ids)
     T, n_corr, idx, dmin, valid = register_batch(batch, src_pred, s, c, dis_thresh, corr)
@@ -155,12 +155,13 @@ def register_items_async(net, its: Sequence[tuple], centers: Sequence[torch.Tens
                          corr: str = "tgt", dis_thresh: float = 0.1, icp=None, icp_dist: float = ICP_MAX_CORR_DIST,
                          icp_iters: int = ICP_MAX_ITER, device: Optional[torch.device] = None,
                          pred_hook: Optional[Callable] = None, lanes: Optional[int] = None,
-                         stream: Optional[torch.cuda.Stream] = None) -> Callable[[], tuple]:
+                         stream: Optional[torch.cuda.Stream] = None, backend: Optional[str] = None) -> Callable[[], tuple]:
     """Enqueue A1-A10 (+ optional GPU ICP) for one batch and return ``finish()``, which waits for the device and gives
     the host arrays of register_items.  Everything between the call and ``finish()`` overlaps the GPU work, which is
     how evaluate_loader hides the host side of batch i-1 and the packing of batch i+1 behind batch i.
     ``stream``: run the WHOLE batch -- one packed forward, search, solve, ICP, result copy -- on that stream and leave the
-    current stream alone (evaluate_loader alternates two such streams between consecutive batches, below)."""
+    current stream alone (evaluate_loader alternates two such streams between consecutive batches, below).
+    ``backend``: the forward's arithmetic for THIS batch (PointTransformer.forward_packed(backend=); None = the model's own)."""
     device = device or next(net.parameters()).device
     if stream is not None:
         lanes = 1
@@ -171,7 +172,7 @@ def register_items_async(net, its: Sequence[tuple], centers: Sequence[torch.Tens
     with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
         outs = _lanes.run(device, parts, lambda rg: _register_lane(
             net, [its[i] for i in rg], [centers[i] for i in rg], [pair_ids[i] for i in rg], corr, dis_thresh, icp, icp_dist,
-            icp_iters, device, pred_hook))
+            icp_iters, device, pred_hook, backend))
         T = torch.cat([o[0] for o in outs])
         T_gt = torch.cat([o[1] for o in outs])
         T_gt_d = torch.cat([o[2] for o in outs])

@@ -72,16 +72,10 @@ def evaluate(net, loader, dis_thresh: float = KITTI_DIS_THRESH, icp_thresh: floa
     """evaluate_kitti.py:23-103.  Pairs are sharded round-robin over ranks when torch.distributed is initialised.
     autocast=True: the forward's matrix products in fp16 with fp32 accumulation, like the reference's `with autocast()`
     (:37) -- a labelled reduced-precision mode, tolerance-tested against the default path, never the default."""
-    if autocast:
-        saved = net.__dict__.get("gemm_backend")  # (instance override, if any; the class attribute is the default)
-        net.gemm_backend = "h1"
-        try:
-            return evaluate(net, loader, dis_thresh, icp_thresh, icp, icp_iters, batch_pairs, skip, verbose, pred_hook, False, in_flight)
-        finally:
-            if saved is None:
-                del net.gemm_backend
-            else:
-                net.gemm_backend = saved
+    # the arithmetic is an argument of every forward of this call, never a module attribute: the model caches one weight image per
+    # backend (PointTransformer._pack_weights), so the switch repacks nothing, frees nothing that a queued forward may still read,
+    # and a net shared with other callers or threads keeps its own mode
+    backend = "h1" if autocast else None
     dataset = getattr(loader, "dataset", loader)
     rank, world = sdist.rank_world()
     ids = [i for i in range(len(dataset)) if i not in skip]
@@ -108,7 +102,7 @@ def evaluate(net, loader, dis_thresh: float = KITTI_DIS_THRESH, icp_thresh: floa
         its = [_strip6(dataset[i]) for i in bid]
         centers = [-(it[2].t() @ it[3]).reshape(3) for it in its]  # evaluate_kitti.py:39
         fin = register_items_async(net, its, centers, bid, "tgt", dis_thresh, icp, icp_thresh, icp_iters, pred_hook=pred_hook,
-                                   stream=streams[k % in_flight])
+                                   stream=streams[k % in_flight], backend=backend)
         pending.append((fin, bid, min(b0 + batch_pairs, len(mine))))
         if len(pending) >= in_flight:
             collect(*pending.pop(0))

@@ -56,6 +56,14 @@ def pe_dim_t(d_model: int = D_MODEL) -> torch.Tensor:
     return 10000 ** (2 * torch.trunc(torch.div(i, 2)) / npf)
 
 
+class _Pack:
+    """One backend's kernel-layout image of the weights (PointTransformer._pack_weights)."""
+
+    def __init__(self, backend, sig, mt, layers, keep, fused, n_cross_batched, event, streams):
+        self.backend, self.sig, self.mt, self.layers, self.keep = backend, sig, mt, layers, keep
+        self.fused, self.n_cross_batched, self.event, self.streams = fused, n_cross_batched, event, streams
+
+
 class PointTransformer(nn.Module):
     def __init__(self, d_model: int = 256, self_layer_num: int = 6, cross_layer_num: int = 6):
         super().__init__()
@@ -75,8 +83,7 @@ class PointTransformer(nn.Module):
                                       nn.ReLU(), nn.Conv1d(d_model, 3, 1))
         # models/pointnet.py:36 builds a RegistrationRender here; it owns no parameters or buffers and is
         # only used when get_imgs=True (training-time GAN loss) -- out of scope, see DESIGN.md.
-        self._packed = None
-        self._packed_sig = None
+        self._packs = {}  # gemm backend -> _Pack: the weights in that backend's kernel layout (built on first use)
         self._ws = None
 
     # ------------------------------------------------------------------ weights -> kernel layout
@@ -115,7 +122,7 @@ class PointTransformer(nn.Module):
         return bool(split and self.fused_tail)
 
     def _signature(self):
-        return (self.gemm_backend, self.fused_tail, self.batched_cross_kv, self.fuse_next_q) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.fused_tail, self.batched_cross_kv, self.fuse_next_q) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _layer_inputs(self):
         """(in_q, in_kv) per layer of _layer_modules() [+ per layer of _stem_tgt_modules()] and the coordinate MLP's input:
@@ -139,10 +146,38 @@ class PointTransformer(nn.Module):
             src_in = ln(mods[ns + j].norm2)
         return ins, tgt_ins, src_in
 
-    def _pack_weights(self):
+    def _pack_weights(self, backend: Optional[str] = None) -> "_Pack":
+        """The weights in the kernel layout of `backend` (default: self.gemm_backend), cached PER BACKEND and rebuilt when a
+        parameter or a fusion switch changes.  A caller that wants another arithmetic for one call (evaluate_kitti's
+        autocast mirror) names it here instead of toggling the module attribute: no repacking on the way in and out,
+        and forwards of the other backend that are still queued keep their images.
+        "h2" whose weights have no fp16 exponent in range (scales.ScaleRangeError: a LayerNorm gain or weight row so large
+        that |x| 2^e <= 2^15 would need e < -24) falls back to "x3" -- the scale-free bf16 x 3 split -- with a warning."""
+        backend = self.gemm_backend if backend is None else backend
+        if backend not in ("h2", "x3", "f32", "h1"):
+            raise ValueError("gemm_backend must be 'h2', 'x3', 'f32' or 'h1', got %r" % (backend,))
         sig = self._signature()
-        if self._packed is not None and sig == self._packed_sig:
-            return self._packed
+        if self._packs and next(iter(self._packs.values())).sig != sig:
+            # the weights changed: every image is stale.  Forwards that read the old ones may still be queued on other streams
+            # (lanes, batches in flight) -- let them finish before their memory is released
+            torch.cuda.synchronize(self.embedding.weight.device) if self.embedding.weight.is_cuda else None
+            self._packs = {}
+        pk = self._packs.get(backend)
+        if pk is not None:
+            return pk
+        try:
+            pk = self._build_pack(backend, sig)
+        except scales.ScaleRangeError as e:
+            if backend != "h2":
+                raise
+            import warnings
+            warnings.warn("scream_amd: gemm_backend 'h2' cannot carry these weights (%s); using 'x3' (bf16 x 3 split, scale free, "
+                          "same fp32-level accuracy at twice the matrix instructions)" % (e,), RuntimeWarning, stacklevel=3)
+            pk = self._pack_weights("x3")
+        self._packs[backend] = pk
+        return pk
+
+    def _build_pack(self, backend: str, sig) -> "_Pack":
         dev = self.embedding.weight.device
         if dev.type != "cuda":
             raise _lib.ScreamHipError("PointTransformer must be on the MI355X (net.to('cuda:0')) before forward; "
@@ -154,9 +189,7 @@ class PointTransformer(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
-        if self.gemm_backend not in ("h2", "x3", "f32", "h1"):
-            raise ValueError("gemm_backend must be 'h2', 'x3', 'f32' or 'h1', got %r" % (self.gemm_backend,))
-        split = {"h2": _lib.SPLIT_H2, "x3": _lib.SPLIT_BF3, "f32": 0, "h1": _lib.SPLIT_H1}[self.gemm_backend]
+        split = {"h2": _lib.SPLIT_H2, "x3": _lib.SPLIT_BF3, "f32": 0, "h1": _lib.SPLIT_H1}[backend]
         fp16_split = split in (_lib.SPLIT_H2, _lib.SPLIT_H1)  # the splits that carry power-of-two operand exponents
 
         def dev_mat(t):  # a weight MATRIX: fp32 [N,K], or its operand planes for the split GEMM; returns (pointer, exponent)
@@ -230,28 +263,26 @@ class PointTransformer(nn.Module):
         if fp16_split:  # coor_mlp (models/pointnet.py:27-33): LayerNorm2 output -> Conv1d + bias, relu -> Conv1d
             mt.e_c0x = scales.exp_for(scales.ln_bound(*coor_in))
             mt.e_c2x = scales.exp_for(scales.lin_bound(c0w, *coor_in, bias=self.coor_mlp[0].bias))
-        self._fused = self._fused_cfg(split)
-        self._n_cross_batched = self.cross_layer_num if mt.wkv_cross else 0
-        self._packed = (mt, (layers, tgt_layers), keep)
-        self._packed_sig = sig
         # the pack kernels and copies above were enqueued on the CURRENT stream; any other stream (a concurrent lane,
         # scream_amd/lanes.py) must order its first use of these buffers behind them (forward_packed waits once per stream)
-        self._packed_event = torch.cuda.Event()
-        self._packed_event.record(torch.cuda.current_stream(dev))
-        self._packed_streams = {torch.cuda.current_stream(dev).cuda_stream}
-        return self._packed
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(dev))
+        return _Pack(backend, sig, mt, (layers, tgt_layers), keep, self._fused_cfg(split), self.cross_layer_num if mt.wkv_cross else 0,
+                     event, {torch.cuda.current_stream(dev).cuda_stream})
 
     # ------------------------------------------------------------------ batched entry
-    def forward_packed(self, batch: PackedBatch, return_feats: bool = False, trace=None):
-        """A1-A6 for every pair of the batch in one C-ABI call; returns src_pred packed [rows_src, 3]."""
-        mt, _layers, _keep = self._pack_weights()
+    def forward_packed(self, batch: PackedBatch, return_feats: bool = False, trace=None, backend: Optional[str] = None):
+        """A1-A6 for every pair of the batch in one C-ABI call; returns src_pred packed [rows_src, 3].
+        backend: the arithmetic of THIS call (default: self.gemm_backend); images are cached per backend (_pack_weights)."""
+        pk = self._pack_weights(backend)
+        mt = pk.mt
         lib = _lib.load()
         dev = batch.xyz.device
-        if ops._stream() not in self._packed_streams:  # first forward of this stream since the weights were packed
-            torch.cuda.current_stream(dev).wait_event(self._packed_event)
-            self._packed_streams.add(ops._stream())
-        need = lib.scream_forward_workspace_bytes(batch.rows_src, batch.rows_total, batch.n_pairs, batch.max_chunks, int(self._fused),
-                                                  self._n_cross_batched)
+        if ops._stream() not in pk.streams:  # first forward of this stream since the weights were packed
+            torch.cuda.current_stream(dev).wait_event(pk.event)
+            pk.streams.add(ops._stream())
+        need = lib.scream_forward_workspace_bytes(batch.rows_src, batch.rows_total, batch.n_pairs, batch.max_chunks, int(pk.fused),
+                                                  pk.n_cross_batched)
         # one scratch buffer per stream: concurrent lanes (scream_amd/lanes.py) run forwards of the same model side by side
         if self._ws is None:
             self._ws = {}
@@ -325,8 +356,7 @@ class DEMTransformer(PointTransformer):
             self.cross.append(_CrossParams(d_model))
         self.coor_mlp = nn.Sequential(nn.Conv1d(d_model, d_model, 1), nn.ReLU(), nn.Conv1d(d_model, d_model, 1),
                                       nn.ReLU(), nn.Conv1d(d_model, 3, 1))
-        self._packed = None
-        self._packed_sig = None
+        self._packs = {}
         self._ws = None
 
     def _layer_modules(self) -> List[_MHAParams]:

@@ -13,9 +13,12 @@ network (models/transformer.py:74-90), so no input can overflow an operand and t
     the denominator only shrinks it; models/transformer.py:38-42):  |att_j| <= max |v_j| <= the bound on v;
   * relu and elu + 1 do not increase a bound by more than 1.
 
-The bound fixes the exponent: e = floor(log2(2^15 / bound)), clamped.  Values below 2^-3 / 2^e lose relative precision
-(the second fp16 plane goes subnormal), i.e. operand values more than 2^18 below their bound -- 2^-40 of the operand's range
-in absolute terms.  Weight matrices take e from their largest |element|.
+The bound fixes the exponent: e = floor(log2(2^15 / bound)).  On the HIGH side it is clamped at E_MAX (a smaller exponent only
+gives headroom away: safe); on the LOW side it is NOT clamped -- a bound above 2^(15 - E_MIN) = 2^39 has no exponent in range
+that keeps the contract, so exp_for raises ScaleRangeError and the model routes such weights to the scale-free bf16 x 3 split
+(gemm_backend "x3"; scream_amd/model.py).  Values below 2^-3 / 2^e lose relative precision (the second fp16 plane goes
+subnormal), i.e. operand values more than 2^18 below their bound -- 2^-40 of the operand's range in absolute terms.  Weight
+matrices take e from their largest |element|.
 """
 from __future__ import annotations
 
@@ -28,14 +31,26 @@ TOP = 2.0 ** 15
 E_MIN, E_MAX = -24, 24  # keeps 2^(e_a + e_w) squared, times a variance, far inside fp32 (csrc/tail_split.hip: tail_scales)
 
 
+class ScaleRangeError(ValueError):
+    """No power-of-two scale inside the kernels' checked range keeps |x| 2^e <= 2^15 for this operand: the fp16 x 2 split cannot
+    carry these weights.  PointTransformer falls back to gemm_backend 'x3' (bf16 x 3, scale free) when it sees this."""
+
+
 def exp_for(bound: float) -> int:
-    """Largest e with bound * 2^e <= 2^15 (clamped); bound = 0 or non-finite -> 0 / ValueError."""
+    """Largest e <= E_MAX with bound * 2^e <= 2^15; bound = 0 -> E_MAX.  Raises ScaleRangeError for a non-finite bound or one
+    that would need e < E_MIN (bound > 2^39): clamping there would silently break the contract (fp16 inf / NaN in the products)."""
     b = float(bound)
     if not math.isfinite(b):
-        raise ValueError("non-finite weights: no fp16 operand scale exists (use gemm_backend='x3')")
+        raise ScaleRangeError("non-finite weights: no fp16 operand scale exists (use gemm_backend='x3')")
     if b <= 0.0:
         return E_MAX
-    return max(E_MIN, min(E_MAX, math.floor(math.log2(TOP / b))))
+    e = math.floor(math.log2(TOP / b))
+    while b * 2.0 ** e > TOP:  # (log2 rounded up across a power of two)
+        e -= 1
+    if e < E_MIN:
+        raise ScaleRangeError("operand bound %.3g needs the exponent %d < %d: outside the range the fp16 x 2 kernels were checked "
+                              "for (use gemm_backend='x3')" % (b, e, E_MIN))
+    return min(E_MAX, e)
 
 
 def w_exp(W: torch.Tensor) -> int:
@@ -63,8 +78,14 @@ def tail_exps(Wm, W1, W2, g1, b1, v_bound: float) -> Dict[str, int]:
     e_h = exp_for(lin_bound(W1, g1, b1))
     e_wm, e_w1, e_w2 = w_exp(Wm), w_exp(W1), w_exp(W2)
     # the accumulator units 2^(e_w + e_a) must stay within what the kernel's LayerNorm arithmetic was checked for
+    # (csrc/tail_split.hip: tail_scales accepts |e_w + e_a| <= 44).  Too HIGH: give headroom away (safe).  Too LOW: no remedy
+    # inside the fp16 split -- raise here, with a message, instead of SCREAM_EINVAL from scream_pack_tail
     e_att = min(e_att, 40 - e_wm)
     e_h = min(e_h, 40 - e_w2)
+    for name, e in (("merge", e_wm + e_att), ("FFN-down", e_w2 + e_h)):
+        if e < -44:
+            raise ScaleRangeError("the %s accumulators would be in units of 2^%d: outside the range the layer-tail kernel's LayerNorm "
+                                  "arithmetic was checked for (use gemm_backend='x3')" % (name, e))
     return {"e_att": e_att, "e_wm": e_wm, "e_m1": e_m1, "e_w1": e_w1, "e_h": e_h, "e_w2": e_w2}
 
 

@@ -82,6 +82,37 @@ def make_state_dict(seed: int, d_model: int = 256, n_self: int = 6, n_cross: int
     return sd
 
 
+def make_trained_like_state_dict(seed: int, d_model: int = 256, n_self: int = 6, n_cross: int = 6, dem: bool = False,
+                                 model_scale_log2: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """Seeded fp32 weights with the statistics training leaves behind -- the stand-in for params/point-generator.pth
+    (evaluate_3d_match.py:188-191), which is not in the image -- where make_state_dict gives the gentlest case default
+    initialisation can: LayerNorm gains log-uniform in [0.05, 8] with three channels per norm a further x 30, LayerNorm
+    biases +- 2, other biases +- 0.5; weight matrices U(-1/sqrt(fan_in), +) with log-normally scaled rows (sigma 0.7) and
+    0.2 % outlier elements x 8 .. 20; every matrix finally times 2^model_scale_log2 (whole-model rescaling).  These are the
+    weights the fp16 x 2 split's weight-derived exponents (scream_amd/scales.py) have to carry."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    for name, shape in (dem_state_dict_keys if dem else state_dict_keys)(d_model, n_self, n_cross):
+        if "norm" in name and name.endswith("weight"):
+            w = np.exp(rng.uniform(math.log(0.05), math.log(8.0), size=shape))
+            w[rng.choice(shape[0], size=3, replace=False)] *= 30.0
+            w *= rng.choice([-1.0, 1.0], size=shape, p=[0.1, 0.9])  # gains do change sign in trained nets
+        elif "norm" in name and name.endswith("bias"):
+            w = rng.uniform(-2.0, 2.0, size=shape)
+        elif name.endswith("bias"):
+            w = rng.uniform(-0.5, 0.5, size=shape)
+        else:
+            fan_in = shape[1]
+            b = 1.0 / math.sqrt(fan_in)
+            w = rng.uniform(-b, b, size=shape)
+            w *= np.exp(rng.normal(0.0, 0.7, size=(shape[0],) + (1,) * (len(shape) - 1)))
+            out = rng.uniform(size=shape) < 0.002
+            w = np.where(out, w * rng.uniform(8.0, 20.0, size=shape), w)
+            w *= 2.0 ** model_scale_log2
+        sd[name] = torch.from_numpy(w.astype(np.float32))
+    return sd
+
+
 def random_rotation(rng: np.random.Generator, max_angle_deg: float = 180.0) -> np.ndarray:
     axis = rng.normal(size=3)
     axis /= np.linalg.norm(axis)

@@ -321,6 +321,46 @@ def test_staging_buffers_alternate_and_grow():
     assert f3.numel() >= 5000                   # slot 1 regrown
 
 
+def test_fp16_exponents_raise_outside_their_range_instead_of_clamping():
+    """scream_amd/scales.py: e = floor(log2(2^15 / bound)).  Clamping it at E_MAX only gives headroom away; clamping at E_MIN
+    would break |x| 2^e <= 2^15 silently (fp16 inf / NaN in the products), so the low side raises ScaleRangeError -- which
+    PointTransformer turns into the scale-free bf16 x 3 path.  Also: the contract holds at every power of two, layer_exps and
+    tail_exps stay inside what scream_pack_tail accepts or raise with a message, never a bare SCREAM_EINVAL."""
+    from scream_amd import scales
+    from scream_amd.model import PointTransformer
+    from scream_amd.synthetic import make_trained_like_state_dict
+    for k in range(-60, 38):
+        for b in (2.0 ** k, 2.0 ** k * 1.0000001, 2.0 ** k * 0.9999999, 3.0 * 2.0 ** k):
+            e = scales.exp_for(b)
+            assert scales.E_MIN <= e <= scales.E_MAX and b * 2.0 ** e <= scales.TOP
+            assert e == scales.E_MAX or b * 2.0 ** (e + 1) > scales.TOP  # the largest such exponent
+    assert scales.exp_for(0.0) == scales.E_MAX and scales.exp_for(2.0 ** 39) == scales.E_MIN
+    for bad in (2.0 ** 39 * 1.001, 1e30, float("inf"), float("nan")):
+        with pytest.raises(scales.ScaleRangeError):
+            scales.exp_for(bad)
+    assert issubclass(scales.ScaleRangeError, ValueError)
+    # exponents of whole models: default-init and trained-like weights at three overall scales stay inside the kernels' range
+    for sd in [make_state_dict(0, 256, 2, 2)] + [make_trained_like_state_dict(5, 256, 2, 2, model_scale_log2=k) for k in (0, 6, -6)]:
+        net = PointTransformer(256, 2, 2)
+        net.load_state_dict(sd)
+        ins = net._layer_inputs()[0]
+        for m, (in_q, in_kv) in zip(net._layer_modules(), ins):
+            ex = scales.layer_exps(m, in_q, in_kv)
+            assert all(scales.E_MIN <= v <= scales.E_MAX for v in ex.values()), ex
+            assert abs(ex["e_wm"] + ex["e_att"]) <= 44 and abs(ex["e_w2"] + ex["e_h"]) <= 44 and abs(ex["e_h"] - ex["e_w1"] - ex["e_m1"]) <= 100
+    # a gain that no exponent >= E_MIN can hold: layer_exps raises (with the remedy in the message)
+    net = PointTransformer(256, 1, 1)
+    net.load_state_dict(make_state_dict(1, 256, 1, 1))
+    with torch.no_grad():
+        net.stem[0].norm1.weight.mul_(2.0 ** 37)
+    with pytest.raises(scales.ScaleRangeError, match="x3"):
+        scales.layer_exps(net.stem[0], (net.pre_norm.weight, net.pre_norm.bias), (net.pre_norm.weight, net.pre_norm.bias))
+    # accumulator units below what the tail's LayerNorm arithmetic was checked for: tail_exps raises, scream_pack_tail is never reached
+    g, b = torch.ones(256), torch.zeros(256)
+    with pytest.raises(scales.ScaleRangeError, match="merge"):
+        scales.tail_exps(torch.full((256, 256), 2.0 ** 38), torch.ones(1024, 256), torch.ones(256, 1024), g, b, 2.0 ** 38)
+
+
 def test_split_kernel_k_loop_has_no_register_spills(tmp_path):
     """gemm_split.hip loads its A operands with inline asm, so the compiler does not know those registers are in flight:
     a spill (scratch store) of one of them inside the k-loop would save stale bytes.  Compile to assembly and require
