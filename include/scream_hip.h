@@ -363,8 +363,24 @@ int scream_point_loss(const float* src_pred, const float* src, const int32_t* sr
  * transforms on entry and the refined ones on return.  Per iteration (one launch): transform the source, thresholded
  * 1-NN (distance <= max_corr_dist), fitness = #corr / N and inlier_rmse = sqrt(mean d^2); stop a pair when
  * both change by less than rel_fitness / rel_rmse or after max_iter updates; otherwise compose the Kabsch
- * update of the correspondences.  fitness_rmse [n_pairs,2] and iters [n_pairs] may be NULL. */
+ * update of the correspondences.  fitness_rmse [n_pairs,2] and iters [n_pairs] may be NULL.  The clouds of a batch may be
+ * packed in any order (the per-chunk partial sums are indexed by a prefix sum of the source lengths).
+ * ASYNCHRONOUS, like every entry point: scream_icp_p2p enqueues the whole schedule (max_iter + 2 launches at most) and never
+ * waits for the device; a pair that has stopped freezes there (its blocks return at their first instruction).  A caller with a
+ * LONG schedule (KITTI: 1000) that wants to stop launching once every pair has stopped asks for the schedule in pieces:
+ * scream_icp_p2p_range enqueues launches [it_begin, it_end) of the same run (launch `it` = evaluate search it - 1, stop or
+ * update, search it; launch max_iter + 1 = the evaluation of the last search; it_begin == 0 also does the set-up, so a run
+ * starts there; every call of a run gets the same arguments and workspace) and then copies the per-pair stopped flags to
+ * done_flags [n_pairs] (device int32, may be NULL) -- the caller copies them to pinned memory behind an event and decides on the
+ * host, between pieces, without ever blocking the stream (scream_amd/ops.py: IcpRun).  T is complete for pair p once its flag
+ * is set.  Results do not depend on how the schedule was cut. */
 int64_t scream_icp_workspace_bytes(int64_t src_rows_total, int64_t ref_rows_total, int32_t n_pairs);
+int scream_icp_p2p_range(const float* src, const float* ref, const int32_t* src_row0, const int32_t* src_len,
+                         const int32_t* ref_row0, const int32_t* ref_len, const float* s, const float* c,
+                         int32_t n_pairs, int32_t max_src_len, int32_t max_ref_len, int64_t src_rows_total,
+                         int64_t ref_rows_total, float max_corr_dist, int32_t max_iter, float rel_fitness,
+                         float rel_rmse, float* T, float* fitness_rmse, int32_t* iters, int32_t it_begin, int32_t it_end,
+                         int32_t* done_flags, void* workspace, int64_t workspace_bytes, void* stream);
 int scream_icp_p2p(const float* src, const float* ref, const int32_t* src_row0, const int32_t* src_len,
                    const int32_t* ref_row0, const int32_t* ref_len, const float* s, const float* c,
                    int32_t n_pairs, int32_t max_src_len, int32_t max_ref_len, int64_t src_rows_total,

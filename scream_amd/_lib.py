@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SCREAM_LIB=<path>: load that build instead (A/B runs of two builds on the same GPU box; never built automatically)
 LIB_PATH = os.environ.get("SCREAM_LIB") or os.path.join(_HERE, "libscream_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -87,6 +87,7 @@ SIGNATURES = {
     "scream_point_loss": (C.c_int, [V, V, V, V, V, V, I32, V, V]),
     "scream_icp_workspace_bytes": (C.c_int64, [I64, I64, I32]),
     "scream_icp_p2p": (C.c_int, [V, V, V, V, V, V, V, V, I32, I32, I32, I64, I64, F32, I32, F32, F32, V, V, V, V, I64, V]),
+    "scream_icp_p2p_range": (C.c_int, [V, V, V, V, V, V, V, V, I32, I32, I32, I64, I64, F32, I32, F32, F32, V, V, V, I32, I32, V, V, I64, V]),
 }
 
 _lib: Optional[C.CDLL] = None

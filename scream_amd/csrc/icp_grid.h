@@ -91,6 +91,7 @@ struct IcpGrid {
 };
 
 int64_t icp_grid_workspace_floats(int64_t ref_rows_total, int32_t n_pairs);
+void icp_grid_carve(int64_t ref_rows_total, int32_t n_pairs, float* work, IcpGrid* out);  // the pointers icp_grid_build fills
 int icp_grid_build(const float* ref_m, const float* ref_prep, const int32_t* r_row0, const int32_t* r_len, int32_t n_pairs,
                    int32_t max_r_len, int64_t ref_rows_total, float radius, float* work, IcpGrid* out, hipStream_t st);
 // nn_search.hip: ref_prep[row] = {b / s, |b / s|^2} (the brute-force search's own preparation) and the padding fill

@@ -145,20 +145,41 @@ int64_t icp_grid_workspace_floats(int64_t ref_rows_total, int32_t n_pairs) {
     return (int64_t)n_pairs * (8 + 2 * (int64_t)ICP_GRID_CELLS + 1) + ref_rows_total * 6 + 5 * 64;
 }
 
-int icp_grid_build(const float* ref_m, const float* ref_prep, const int32_t* r_row0, const int32_t* r_len, int32_t n_pairs,
-                   int32_t max_r_len, int64_t ref_rows_total, float radius, float* work, IcpGrid* out, hipStream_t st) {
+// where the grid of a workspace lives: a pure function of (sizes, work), so a later call of the same run finds the grid an
+// earlier one built (scream_icp_p2p_range)
+struct GridCarve {
+    GridParam* gp;
+    int32_t *count, *cursor, *cell_of, *sorted_idx;
+    float* sorted_prep;
+};
+static GridCarve carve_grid(int64_t ref_rows_total, int32_t n_pairs, float* work) {
     float* w = work;
     auto take = [&](int64_t n) { float* r = w; w += (n + 63) / 64 * 64; return r; };
-    GridParam* gp = reinterpret_cast<GridParam*>(take((int64_t)n_pairs * 8));
-    int32_t* count = reinterpret_cast<int32_t*>(take((int64_t)n_pairs * (ICP_GRID_CELLS + 1)));
-    int32_t* cursor = reinterpret_cast<int32_t*>(take((int64_t)n_pairs * ICP_GRID_CELLS));
-    int32_t* cell_of = reinterpret_cast<int32_t*>(take(ref_rows_total));
-    float* sorted_prep = take(ref_rows_total * 4);
-    int32_t* sorted_idx = reinterpret_cast<int32_t*>(take(ref_rows_total));
-    out->params = gp;
-    out->start = count;
-    out->sorted_prep = sorted_prep;
-    out->sorted_idx = sorted_idx;
+    GridCarve c;
+    c.gp = reinterpret_cast<GridParam*>(take((int64_t)n_pairs * 8));
+    c.count = reinterpret_cast<int32_t*>(take((int64_t)n_pairs * (ICP_GRID_CELLS + 1)));
+    c.cursor = reinterpret_cast<int32_t*>(take((int64_t)n_pairs * ICP_GRID_CELLS));
+    c.cell_of = reinterpret_cast<int32_t*>(take(ref_rows_total));
+    c.sorted_prep = take(ref_rows_total * 4);
+    c.sorted_idx = reinterpret_cast<int32_t*>(take(ref_rows_total));
+    return c;
+}
+
+void icp_grid_carve(int64_t ref_rows_total, int32_t n_pairs, float* work, IcpGrid* out) {
+    const GridCarve c = carve_grid(ref_rows_total, n_pairs, work);
+    out->params = c.gp;
+    out->start = c.count;
+    out->sorted_prep = c.sorted_prep;
+    out->sorted_idx = c.sorted_idx;
+}
+
+int icp_grid_build(const float* ref_m, const float* ref_prep, const int32_t* r_row0, const int32_t* r_len, int32_t n_pairs,
+                   int32_t max_r_len, int64_t ref_rows_total, float radius, float* work, IcpGrid* out, hipStream_t st) {
+    const GridCarve cv = carve_grid(ref_rows_total, n_pairs, work);
+    GridParam* gp = cv.gp;
+    int32_t *count = cv.count, *cursor = cv.cursor, *cell_of = cv.cell_of, *sorted_idx = cv.sorted_idx;
+    float* sorted_prep = cv.sorted_prep;
+    icp_grid_carve(ref_rows_total, n_pairs, work, out);
     hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t) * (size_t)n_pairs * (ICP_GRID_CELLS + 1), st);
     if (e != hipSuccess) return (int)e;
     grid_params_kernel<<<dim3(n_pairs), dim3(256), 0, st>>>(ref_m, r_row0, r_len, radius * 1.01f, gp);

@@ -420,7 +420,8 @@ struct IcpArgs {
     const int32_t* src_len;
     float* Tbuf;         // [2][n_pairs][16]: T of search it lives at parity it & 1
     IcpState* state;     // [2][n_pairs]: evaluation of search e at parity e & 1
-    double* part;        // [2][n_chunks_total][ICP_NP]: partials of search it at parity it & 1; chunk c of pair p = src_row0[p] / 256 + p + c
+    double* part;        // [2][n_chunks_total][ICP_NP]: partials of search it at parity it & 1; chunk c of pair p = chunk0[p] + c
+    const int32_t* chunk0;  // [n_pairs] exclusive prefix sum of icp_chunks(src_len[p]) (icp_chunk0_kernel): collision-free for ANY order / overlap of the clouds
     int32_t* done;       // [n_pairs] 0 -> 1, once
     int32_t* act_len;    // [n_pairs] src_len, 0 once done (the brute-force yardstick's kernels take their work from it)
     int64_t part_stride; // n_chunks_total * ICP_NP
@@ -432,7 +433,19 @@ struct IcpArgs {
 };
 
 __device__ __forceinline__ int icp_chunks(int n) { return n > 0 ? (n + 255) / 256 : 1; }  // (an empty source still has its block 0)
-__device__ __forceinline__ int64_t icp_chunk0(const IcpArgs& a, int p) { return (int64_t)a.src_row0[p] / 256 + p; }
+__device__ __forceinline__ int64_t icp_chunk0(const IcpArgs& a, int p) { return a.chunk0[p]; }
+
+// chunk0[p] = sum_{q < p} icp_chunks(src_len[q]); one thread (n_pairs is a batch size).  Until round 3 the slots were derived from
+// src_row0[p] / 256 + p, which is collision-free only for clouds packed in ascending, non-overlapping order -- true for PackedBatch,
+// not promised by the C ABI.
+__global__ void icp_chunk0_kernel(const int32_t* __restrict__ src_len, int32_t n_pairs, int32_t* __restrict__ chunk0) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int32_t acc = 0;
+    for (int p = 0; p < n_pairs; ++p) {
+        chunk0[p] = acc;
+        acc += icp_chunks(src_len[p]);
+    }
+}
 
 // Whole block (256 threads).  Evaluates search e = it - 1 of pair p from its partials; returns (block-uniform) whether the pair
 // stops.  If it goes on, T_sh (LDS) holds T_it = dT . T_e.  `writer`: this block publishes state / done / outputs / T_it.
@@ -669,19 +682,19 @@ extern "C" int64_t scream_icp_workspace_bytes(int64_t src_rows_total, int64_t re
     if (src_rows_total < 0 || ref_rows_total < 0 || n_pairs < 0) return SCREAM_EINVAL;
     // src metric + transformed src (3 floats each), ref metric (3) + nn ref_prep (4), keys (2), idx, dmin, valid, per pair: ones,
     // T x 2 (32), state x 2 (4), done, act_len; the chunk partials (2 parities x 17 doubles) + the target grid of icp_grid.hip
-    return (src_rows_total * (3 + 3 + 2 + 1 + 1 + 1) + ref_rows_total * (3 + 4) + (int64_t)n_pairs * (1 + 32 + 4 + 1 + 1) +
+    return (src_rows_total * (3 + 3 + 2 + 1 + 1 + 1) + ref_rows_total * (3 + 4) + (int64_t)n_pairs * (1 + 32 + 4 + 1 + 1 + 1) + 64 +
             icp_chunks_total(src_rows_total, n_pairs) * (2 * ICP_NP * 2) +
             scream_internal::icp_grid_workspace_floats(ref_rows_total, n_pairs)) * 4 + 16384;
 }
 
-extern "C" int scream_icp_p2p(const float* src, const float* ref, const int32_t* src_row0, const int32_t* src_len,
-                              const int32_t* ref_row0, const int32_t* ref_len, const float* s, const float* c,
-                              int32_t n_pairs, int32_t max_src_len, int32_t max_ref_len, int64_t src_rows_total,
-                              int64_t ref_rows_total, float max_corr_dist, int32_t max_iter, float rel_fitness,
-                              float rel_rmse, float* T, float* fitness_rmse, int32_t* iters, void* workspace,
-                              int64_t workspace_bytes, void* stream) {
+extern "C" int scream_icp_p2p_range(const float* src, const float* ref, const int32_t* src_row0, const int32_t* src_len,
+                                    const int32_t* ref_row0, const int32_t* ref_len, const float* s, const float* c,
+                                    int32_t n_pairs, int32_t max_src_len, int32_t max_ref_len, int64_t src_rows_total,
+                                    int64_t ref_rows_total, float max_corr_dist, int32_t max_iter, float rel_fitness,
+                                    float rel_rmse, float* T, float* fitness_rmse, int32_t* iters, int32_t it_begin,
+                                    int32_t it_end, int32_t* done_flags, void* workspace, int64_t workspace_bytes, void* stream) {
     SCREAM_REQUIRE(src && ref && src_row0 && src_len && ref_row0 && ref_len && s && c && T && workspace, SCREAM_EINVAL);
-    SCREAM_REQUIRE(n_pairs >= 0 && max_iter >= 0 && max_corr_dist > 0.f, SCREAM_EINVAL);
+    SCREAM_REQUIRE(n_pairs >= 0 && max_iter >= 0 && max_corr_dist > 0.f && it_begin >= 0 && it_end >= it_begin, SCREAM_EINVAL);
     SCREAM_REQUIRE(workspace_bytes >= scream_icp_workspace_bytes(src_rows_total, ref_rows_total, n_pairs), SCREAM_EINVAL);
     if (n_pairs == 0) return 0;
     hipStream_t st = as_stream(stream);
@@ -705,6 +718,8 @@ extern "C" int scream_icp_p2p(const float* src, const float* ref, const int32_t*
     a.act_len = reinterpret_cast<int32_t*>(take(n_pairs));
     a.part_stride = icp_chunks_total(src_rows_total, n_pairs) * ICP_NP;
     a.part = reinterpret_cast<double*>(take(a.part_stride * 2 * 2));
+    int32_t* chunk0 = reinterpret_cast<int32_t*>(take(n_pairs));
+    a.chunk0 = chunk0;
     a.n_pairs = n_pairs;
     a.max_iter = max_iter;
     a.rel_fitness = rel_fitness;
@@ -718,33 +733,42 @@ extern "C" int scream_icp_p2p(const float* src, const float* ref, const int32_t*
     const char* brute_env = getenv("SCREAM_ICP_BRUTE");
     const bool brute = brute_env && brute_env[0] == '1';
 
-    hipError_t e = hipMemsetAsync(a.done, 0, sizeof(int32_t) * n_pairs, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(a.state, 0, sizeof(IcpState) * 2 * n_pairs, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyAsync(a.act_len, src_len, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyAsync(a.Tbuf, T, sizeof(float) * 16 * n_pairs, hipMemcpyDeviceToDevice, st);  // T_0: parity 0
-    if (e != hipSuccess) return (int)e;
-    // ones[p] = 1.0f: the search's "scale" (it divides by it), since these clouds are already metric
-    fill_f32_kernel<<<dim3((n_pairs + 255) / 256), dim3(256), 0, st>>>(ones, 1.0f, n_pairs);
-    if (max_src_len > 0)
-        icp_to_metric_kernel<<<dim3((max_src_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(src, src_row0, src_len, s, c, src_m);
-    if (max_ref_len > 0)
-        icp_to_metric_kernel<<<dim3((max_ref_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(ref, ref_row0, ref_len, s, c, ref_m);
-    SCREAM_LAUNCH_CHECK();
+    hipError_t e = hipSuccess;
     scream_internal::IcpGrid grid{};
-    if (!brute) {  // the targets do not move: prepare and bin them once (icp_grid.hip)
-        int rc = scream_internal::nn_prepare_targets(ref_m, ref_row0, ref_len, ones, n_pairs, max_ref_len, ref_prep, st);
-        if (rc != 0) return rc;
-        rc = scream_internal::icp_grid_build(ref_m, ref_prep, ref_row0, ref_len, n_pairs, max_ref_len, ref_rows_total, max_corr_dist,
-                                             grid_work, &grid, st);
-        if (rc != 0) return rc;
+    if (!brute)  // pointers into grid_work: a pure function of the arguments (every call of a run sees the same ones)
+        scream_internal::icp_grid_carve(ref_rows_total, n_pairs, grid_work, &grid);
+    if (it_begin == 0) {  // set-up: flags, T_0, metric clouds, the target grid
+        e = hipMemsetAsync(a.done, 0, sizeof(int32_t) * n_pairs, st);
+        if (e != hipSuccess) return (int)e;
+        e = hipMemsetAsync(a.state, 0, sizeof(IcpState) * 2 * n_pairs, st);
+        if (e != hipSuccess) return (int)e;
+        e = hipMemcpyAsync(a.act_len, src_len, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+        e = hipMemcpyAsync(a.Tbuf, T, sizeof(float) * 16 * n_pairs, hipMemcpyDeviceToDevice, st);  // T_0: parity 0
+        if (e != hipSuccess) return (int)e;
+        icp_chunk0_kernel<<<dim3(1), dim3(64), 0, st>>>(src_len, n_pairs, chunk0);
+        // ones[p] = 1.0f: the search's "scale" (it divides by it), since these clouds are already metric
+        fill_f32_kernel<<<dim3((n_pairs + 255) / 256), dim3(256), 0, st>>>(ones, 1.0f, n_pairs);
+        if (max_src_len > 0)
+            icp_to_metric_kernel<<<dim3((max_src_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(src, src_row0, src_len, s, c, src_m);
+        if (max_ref_len > 0)
+            icp_to_metric_kernel<<<dim3((max_ref_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(ref, ref_row0, ref_len, s, c, ref_m);
+        SCREAM_LAUNCH_CHECK();
+        if (!brute) {  // the targets do not move: prepare and bin them once (icp_grid.hip)
+            int rc = scream_internal::nn_prepare_targets(ref_m, ref_row0, ref_len, ones, n_pairs, max_ref_len, ref_prep, st);
+            if (rc != 0) return rc;
+            rc = scream_internal::icp_grid_build(ref_m, ref_prep, ref_row0, ref_len, n_pairs, max_ref_len, ref_rows_total, max_corr_dist,
+                                                 grid_work, &grid, st);
+            if (rc != 0) return rc;
+        }
     }
     const dim3 chunks((max_src_len > 0 ? max_src_len + 255 : 256) / 256, n_pairs);
-    std::vector<int32_t> host_done;
     // launch `it` = [evaluate search it - 1, stop or update T] + search it; search max_iter is evaluated by a last pose launch
-    for (int it = 0; it <= max_iter; ++it) {
+    // (launch index max_iter + 1).  NOTHING here waits for the device: a pair that has stopped freezes on the device (its
+    // blocks return at their first instruction), and a caller that wants to stop LAUNCHING early asks for the schedule in
+    // pieces and reads done_flags between them (scream_hip.h).
+    const int last = it_end < max_iter + 1 ? it_end : max_iter + 1;
+    for (int it = it_begin; it < last; ++it) {
         if (brute) {  // SCREAM_ICP_BRUTE=1, the yardstick of the tests: the same steps as separate launches around scream_nn_search
             if (it > 0) icp_pose_kernel<<<dim3(n_pairs), dim3(256), 0, st>>>(a, it);
             if (max_src_len > 0)
@@ -760,22 +784,27 @@ extern "C" int scream_icp_p2p(const float* src, const float* ref, const int32_t*
                                                           grid.start, grid.sorted_prep, grid.sorted_idx, max_corr_dist * max_corr_dist, it);
         }
         SCREAM_LAUNCH_CHECK();
-        // Long schedules (KITTI asks for up to 1000 iterations, evaluate_kitti.py:69) usually converge in tens:
-        // look at the flags every 32 iterations and stop launching once every pair is done.  Short schedules (the
-        // 30-iteration default) never synchronise: converged pairs have frozen on the device and cost no search work,
-        // and a host that does not block here can keep the other batches queued.
-        if (max_iter > 64 && (it & 31) == 31 && it < max_iter) {
-            host_done.resize(n_pairs);
-            e = hipMemcpyAsync(host_done.data(), a.done, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, st);
-            if (e != hipSuccess) return (int)e;
-            e = hipStreamSynchronize(st);
-            if (e != hipSuccess) return (int)e;
-            bool all_done = true;
-            for (int32_t d : host_done) all_done = all_done && d;
-            if (all_done) return 0;
-        }
     }
-    icp_pose_kernel<<<dim3(n_pairs), dim3(256), 0, st>>>(a, max_iter + 1);
-    SCREAM_LAUNCH_CHECK();
+    if (it_end > max_iter + 1 && it_begin <= max_iter + 1) {
+        icp_pose_kernel<<<dim3(n_pairs), dim3(256), 0, st>>>(a, max_iter + 1);
+        SCREAM_LAUNCH_CHECK();
+    }
+    if (done_flags) {
+        e = hipMemcpyAsync(done_flags, a.done, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
     return 0;
+}
+
+// the whole schedule in one call: max_iter + 2 launches at most, none of them waited for
+extern "C" int scream_icp_p2p(const float* src, const float* ref, const int32_t* src_row0, const int32_t* src_len,
+                              const int32_t* ref_row0, const int32_t* ref_len, const float* s, const float* c,
+                              int32_t n_pairs, int32_t max_src_len, int32_t max_ref_len, int64_t src_rows_total,
+                              int64_t ref_rows_total, float max_corr_dist, int32_t max_iter, float rel_fitness,
+                              float rel_rmse, float* T, float* fitness_rmse, int32_t* iters, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+    SCREAM_REQUIRE(max_iter >= 0 && max_iter < (1 << 30), SCREAM_EINVAL);
+    return scream_icp_p2p_range(src, ref, src_row0, src_len, ref_row0, ref_len, s, c, n_pairs, max_src_len, max_ref_len, src_rows_total,
+                                ref_rows_total, max_corr_dist, max_iter, rel_fitness, rel_rmse, T, fitness_rmse, iters, 0, max_iter + 2,
+                                nullptr, workspace, workspace_bytes, stream);
 }

@@ -132,22 +132,38 @@ def _register_lane(net, its, centers, pair_ids, corr, dis_thresh, icp, icp_dist,
         src_pred = pred_hook(batch, src_pred, pair_ids)
     T, n_corr, idx, dmin, valid = register_batch(batch, src_pred, s, c, dis_thresh, corr)
     re, te = ops.transformation_error_batched(T, T_gt_d)
+    out = {"T_gt": T_gt, "T_gt_d": T_gt_d, "run": None}
     if isinstance(icp, str):
         if icp != "gpu":
             raise ValueError("icp must be None, 'gpu' or a callable")
         # evaluate_3d_match.py:106-119 on the MI355X for the whole batch: refine from the Kabsch pose, keep the
         # refinement only where it improves both RE and TE against the ground truth (:117)
+        T0, re0, te0 = T, re, te
+
+        def accept(T2):
+            re2, te2 = ops.transformation_error_batched(T2, T_gt_d)
+            better = (re2 <= re0) & (te2 <= te0)
+            return torch.where(better[:, None, None], T2, T0), torch.where(better, re2, re0), torch.where(better, te2, te0)
+
         tgt_row0 = (batch.tgt_row0 - batch.rows_src).contiguous()
-        T2, _, _ = ops.icp_p2p(batch.xyz[: batch.rows_src], batch.xyz[batch.rows_src:], batch.src_row0,
-                               batch.src_len_dev, tgt_row0, batch.tgt_len_dev, s, c, T, max(batch.src_len),
-                               max(batch.tgt_len), icp_dist, icp_iters)
-        re2, te2 = ops.transformation_error_batched(T2, T_gt_d)
-        better = (re2 <= re) & (te2 <= te)
-        T = torch.where(better[:, None, None], T2, T)
-        re, te = torch.where(better, re2, re), torch.where(better, te2, te)
+        icp_args = (batch.xyz[: batch.rows_src], batch.xyz[batch.rows_src:], batch.src_row0, batch.src_len_dev, tgt_row0,
+                    batch.tgt_len_dev, s, c, T, max(batch.src_len), max(batch.tgt_len), icp_dist, icp_iters)
+        if icp_iters <= ops.ICP_ASYNC_ITERS:  # the whole schedule in one asynchronous call
+            T, re, te = accept(ops.icp_p2p(*icp_args)[0])
+        else:
+            # A long schedule (KITTI: 1000 iterations) usually stops within tens: its first piece is enqueued here together with
+            # everything behind the ICP, computed as if every pair had stopped by then; finish() reads the stopped flags when it
+            # collects the batch and, only if a pair was still moving, enqueues more pieces and this tail again.  The host never
+            # waits while it enqueues (until round 3 the C call itself synchronised every 32 iterations).
+            run = ops.IcpRun(*icp_args)
+            run.advance(ops.ICP_ASYNC_ITERS)
+            run.accept, run.stream = accept, torch.cuda.current_stream(device)
+            out["run"] = run
+            T, re, te = accept(run.T)
     # PointTransformer.loss per pair (models/pointnet.py:93-99, evaluate_3d_match.py:86) for the whole batch in one launch
     loss = ops.point_loss(src_pred.contiguous(), batch.xyz[: batch.rows_src], batch.src_row0, batch.src_len_dev, rot_d, trans_d)
-    return T, T_gt, T_gt_d, re, te, loss
+    out.update(T=T, re=re, te=te, loss=loss)
+    return out
 
 
 @torch.no_grad()
@@ -173,23 +189,53 @@ def register_items_async(net, its: Sequence[tuple], centers: Sequence[torch.Tens
         outs = _lanes.run(device, parts, lambda rg: _register_lane(
             net, [its[i] for i in rg], [centers[i] for i in rg], [pair_ids[i] for i in rg], corr, dis_thresh, icp, icp_dist,
             icp_iters, device, pred_hook, backend))
-        T = torch.cat([o[0] for o in outs])
-        T_gt = torch.cat([o[1] for o in outs])
-        T_gt_d = torch.cat([o[2] for o in outs])
-        re, te = torch.cat([o[3] for o in outs]), torch.cat([o[4] for o in outs])
-        loss = torch.cat([o[5] for o in outs]).reshape(-1)
-        # one small device buffer -> one asynchronous D2H copy into pinned memory
-        flat = torch.cat([T.reshape(-1), re, te, loss]).float()
-        host = torch.empty(flat.shape, dtype=torch.float32, pin_memory=True)
-        host.copy_(flat, non_blocking=True)
-        done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(device))
-    keep = [outs, flat]  # lane-stream allocations stay referenced until the copy has been consumed
+        pub = {}
+
+        def publish():  # one small device buffer -> one asynchronous D2H copy into pinned memory
+            T = torch.cat([o["T"] for o in outs])
+            re, te = torch.cat([o["re"] for o in outs]), torch.cat([o["te"] for o in outs])
+            loss = torch.cat([o["loss"] for o in outs]).reshape(-1)
+            flat = torch.cat([T.reshape(-1), re, te, loss]).float()
+            host = torch.empty(flat.shape, dtype=torch.float32, pin_memory=True)
+            host.copy_(flat, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(device))
+            pub.update(flat=flat, host=host, done=done)
+
+        publish()
+        T_gt = torch.cat([o["T_gt"] for o in outs])
+        T_gt_d = torch.cat([o["T_gt_d"] for o in outs])
+    keep = [outs, pub]  # lane-stream allocations stay referenced until the copy has been consumed
+
+    def continue_long_icp():
+        """Only for schedules longer than ops.ICP_ASYNC_ITERS whose first piece left a pair moving: more pieces, then the ICP's
+        tail and the result copy again (scream_amd/ops.py: IcpRun).  Runs when the batch is COLLECTED, i.e. behind the enqueueing
+        of the following batches -- the device has their work while the host waits here."""
+        redo = False
+        for o in outs:
+            run = o["run"]
+            if run is None or run.all_stopped():
+                continue
+            redo = True
+            with torch.cuda.stream(run.stream):
+                piece = 2 * ops.ICP_ASYNC_ITERS
+                while not run.all_stopped():
+                    run.advance(piece)
+                    piece *= 2
+                o["T"], o["re"], o["te"] = run.accept(run.T)
+                ev = torch.cuda.Event()
+                ev.record(run.stream)
+            with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                torch.cuda.current_stream(device).wait_event(ev)
+        if redo:
+            with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                publish()
 
     def finish():
-        done.synchronize()
+        continue_long_icp()
+        pub["done"].synchronize()
         B = len(its)
-        h = host.numpy().astype(np.float64)
+        h = pub["host"].numpy().astype(np.float64)
         T_h = h[:16 * B].reshape(B, 4, 4).astype(np.float32)
         re_h, te_h, loss_h = h[16 * B:17 * B].copy(), h[17 * B:18 * B].copy(), h[18 * B:19 * B].copy()
         if callable(icp):  # e.g. a wrapper around o3d.registration_icp: (item, T_init) -> T

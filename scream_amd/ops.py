@@ -357,3 +357,53 @@ def icp_p2p(src, ref, src_row0, src_len, ref_row0, ref_len, s, c, T_init, max_sr
                              float(rel_fitness), float(rel_rmse), _p(T), _p(fr), _p(iters, torch.int32),
                              ws.data_ptr(), need, _stream()), "scream_icp_p2p")
     return T, fr, iters
+
+
+ICP_ASYNC_ITERS = 64  # schedules up to this many iterations are enqueued whole (icp_p2p); longer ones in pieces (IcpRun)
+
+
+class IcpRun:
+    """A LONG ICP schedule (KITTI: up to 1000 iterations, evaluate_kitti.py:64-70) enqueued in pieces, so that launching stops
+    once every pair has stopped WITHOUT the host ever waiting inside the C ABI (scream_icp_p2p_range): ``advance(n)`` enqueues the
+    next n launches on the current stream and, behind them, a copy of the per-pair stopped flags into pinned memory + an event;
+    ``all_stopped()`` waits for THAT event only (the caller calls it when it collects the batch, i.e. after the following batches
+    were enqueued) and reads the flags.  ``T`` holds the refined transform of every pair whose flag is set; ``finish()`` enqueues
+    what is left of the schedule.  Results are those of icp_p2p whatever the piece sizes (tests/test_gpu_evaluate.py)."""
+
+    def __init__(self, src, ref, src_row0, src_len, ref_row0, ref_len, s, c, T_init, max_src_len: int, max_ref_len: int,
+                 max_corr_dist: float, max_iter: int, rel_fitness: float = 1e-6, rel_rmse: float = 1e-6):
+        self.lib = _lib.load()
+        n = s.shape[0]
+        dev = src.device
+        self.n, self.max_iter, self.next_it = n, int(max_iter), 0
+        self.T = T_init.detach().clone().contiguous().float()
+        self.fr = torch.empty(n, 2, device=dev, dtype=torch.float32)
+        self.iters = torch.empty(n, device=dev, dtype=torch.int32)
+        self.flags = torch.zeros(n, device=dev, dtype=torch.int32)
+        self.flags_host = torch.zeros(n, dtype=torch.int32, pin_memory=True)
+        need = self.lib.scream_icp_workspace_bytes(src.shape[0], ref.shape[0], n)
+        self.ws = torch.empty(need, device=dev, dtype=torch.uint8)
+        self._keep = (src, ref, src_row0, src_len, ref_row0, ref_len, s, c)
+        self._args = (_p(src), _p(ref), _p(src_row0, torch.int32), _p(src_len, torch.int32), _p(ref_row0, torch.int32),
+                      _p(ref_len, torch.int32), _p(s), _p(c), n, int(max_src_len), int(max_ref_len), src.shape[0], ref.shape[0],
+                      float(max_corr_dist), int(max_iter), float(rel_fitness), float(rel_rmse), _p(self.T), _p(self.fr),
+                      _p(self.iters, torch.int32))
+        self.event = None
+
+    @property
+    def launches_left(self) -> int:
+        return self.max_iter + 2 - self.next_it
+
+    def advance(self, n_launches: int) -> None:
+        end = min(self.next_it + int(n_launches), self.max_iter + 2)
+        check(self.lib.scream_icp_p2p_range(*self._args, self.next_it, end, _p(self.flags, torch.int32), self.ws.data_ptr(),
+                                            self.ws.numel(), _stream()), "scream_icp_p2p_range")
+        self.next_it = end
+        self.flags_host.copy_(self.flags, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(self.T.device))
+
+    def all_stopped(self) -> bool:
+        """Waits for the flags of the last advance() (not for the stream's later work) and reads them."""
+        self.event.synchronize()
+        return self.launches_left == 0 or bool(self.flags_host.all())

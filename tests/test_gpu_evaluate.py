@@ -181,6 +181,83 @@ def test_gpu_icp_grid_search_equals_brute_force_bitwise(kind, monkeypatch):
         assert fit[3] == 0.0                 # the displaced source found nothing, on both paths
 
 
+def _icp_problem(n_pairs=3, seed0=80, perturb_deg=1.0):
+    from scream_amd.packing import PackedBatch
+    rng = np.random.default_rng(3)
+    items = [SyntheticPairs("3dmatch", n_pairs, seed0=seed0)[i] for i in range(n_pairs)]
+    srcs, tgts = [it[0].to(DEV) for it in items], [it[1].to(DEV) for it in items]
+    batch = PackedBatch.from_pairs(srcs, tgts, None)
+    s = torch.tensor([it[4] for it in items], dtype=torch.float32, device=DEV)
+    c = torch.stack([it[7] for it in items]).to(DEV)
+    T0 = []
+    for it in items:
+        Tgt = O.gt_pose_metric(it[2], it[3], it[4], it[7]).double().numpy()
+        ang = np.radians(perturb_deg)
+        P = np.eye(4)
+        P[:3, :3] = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+        P[:3, 3] = rng.normal(scale=0.02, size=3)
+        T0.append(P @ Tgt)
+    return batch, s, c, torch.from_numpy(np.stack(T0)).float().to(DEV)
+
+
+def test_gpu_icp_in_pieces_equals_the_whole_schedule_and_never_blocks():
+    """scream_icp_p2p_range (round 4): a long schedule enqueued in pieces -- the caller reads the stopped flags between pieces and
+    stops launching -- gives bit for bit what the whole schedule gives in one call, whatever the piece sizes; the flags come
+    back set exactly for the pairs that have stopped; and the one-call form (max_iter = 1000: a thousand launches, most of them
+    on frozen pairs) no longer synchronises with the host inside the C ABI (until round 3 it did, every 32 iterations)."""
+    from scream_amd import ops
+    batch, s, c, T0 = _icp_problem()
+    tgt_row0 = (batch.tgt_row0 - batch.rows_src).contiguous()
+    args = (batch.xyz[: batch.rows_src], batch.xyz[batch.rows_src:], batch.src_row0, batch.src_len_dev, tgt_row0,
+            batch.tgt_len_dev, s, c, T0, max(batch.src_len), max(batch.tgt_len), 0.1, 1000)
+    want = ops.icp_p2p(*args)  # all 1002 launches
+    assert int(want[2].max()) < 200  # (these pairs stop long before the cap: the rest of the schedule ran on frozen pairs)
+    for first, piece in ((64, 128), (7, 5), (1, 1)):
+        run = ops.IcpRun(*args)
+        run.advance(first)
+        n_adv = 1
+        while not run.all_stopped():
+            run.advance(piece)
+            n_adv += 1
+        assert run.next_it < 1002 and n_adv < 400  # launching stopped early
+        for a, b in zip((run.T, run.fr, run.iters), want):
+            assert torch.equal(a, b), (first, piece)
+        assert bool(run.flags_host.all())
+    # the flags are per pair: after a piece shorter than the slowest pair needs, only the pairs that have stopped are flagged
+    run = ops.IcpRun(*args)
+    run.advance(int(want[2].min()) + 2)
+    run.event.synchronize()
+    assert run.flags_host.tolist() == [int(v) for v in (want[2] <= int(want[2].min())).tolist()]
+    # asynchronous: enqueueing the whole 1000-iteration schedule behind a long-running kernel returns before that kernel ends
+    big = torch.randn(8192, 8192, device=DEV)
+    torch.cuda.synchronize()
+    ev = torch.cuda.Event()
+    for _ in range(8):
+        big @ big
+    ev.record()
+    ops.icp_p2p(*args)
+    assert not ev.query(), "scream_icp_p2p waited for the device"
+    torch.cuda.synchronize()
+
+
+def test_gpu_icp_does_not_depend_on_the_order_of_the_clouds():
+    """The per-chunk partial sums of a pair are indexed by a prefix sum of the source lengths (round 4), not by src_row0 / 256 + p:
+    a C-ABI caller whose pairs sit in the buffers in ANOTHER order (pair 0's rows behind pair 1's) gets the same poses, bit for bit,
+    as PackedBatch's ascending order gives."""
+    from scream_amd import ops
+    batch, s, c, T0 = _icp_problem(2, seed0=84)
+    tgt_row0 = (batch.tgt_row0 - batch.rows_src).contiguous()
+    src, ref = batch.xyz[: batch.rows_src], batch.xyz[batch.rows_src:]
+    args = (src, ref, batch.src_row0, batch.src_len_dev, tgt_row0, batch.tgt_len_dev, s, c, T0, max(batch.src_len), max(batch.tgt_len), 0.1, 30)
+    want = ops.icp_p2p(*args)
+    perm = torch.tensor([1, 0], device=DEV)
+    sw = lambda t: t[perm].contiguous()
+    got = ops.icp_p2p(src, ref, sw(batch.src_row0), sw(batch.src_len_dev), sw(tgt_row0), sw(batch.tgt_len_dev), sw(s), sw(c), sw(T0),
+                      max(batch.src_len), max(batch.tgt_len), 0.1, 30)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b[perm.to(b.device)])
+
+
 def test_gpu_icp_matches_oracle_iteration_by_iteration():
     """The same loop, compared where it is well defined: ONE update from the same start uses the same correspondences
     on both sides, so device and oracle must agree to 1e-4 Frobenius.  The starts are the oracle's own iterates
@@ -297,6 +374,17 @@ def test_batches_in_flight_do_not_change_results():
     kd = SyntheticKittiPairs(5)
     kouts = [evaluate(net, kd, batch_pairs=2, skip=(), verbose=False, icp_iters=40, in_flight=n) for n in (1, 4)]
     assert kouts[0] == kouts[1], kouts
+    # a LONG schedule goes out in pieces (ops.IcpRun: the first 64 launches with the batch, the rest -- only if a pair is still
+    # moving -- when the batch is collected); same numbers as the whole schedule in one asynchronous call
+    from scream_amd import ops
+    long_pieces = evaluate(net, kd, batch_pairs=2, skip=(), verbose=False, icp_iters=300, in_flight=3)
+    old = ops.ICP_ASYNC_ITERS
+    ops.ICP_ASYNC_ITERS = 1 << 20
+    try:
+        long_whole = evaluate(net, kd, batch_pairs=2, skip=(), verbose=False, icp_iters=300, in_flight=3)
+    finally:
+        ops.ICP_ASYNC_ITERS = old
+    assert long_pieces == long_whole, (long_pieces, long_whole)
 
 
 def test_kitti_harness_large_clouds():

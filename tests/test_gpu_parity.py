@@ -890,7 +890,7 @@ def test_forward_with_and_without_the_fused_query_projection(golden):
         net = net.to("cuda:0").eval()
         net.fuse_next_q = on
         outs[on] = net.forward_batch([dev(src)], [dev(tgt)])[0].cpu()
-        mt, (layers, _), _keep = net._pack_weights()
+        layers = net._pack_weights().layers[0]
         assert [int(L.tail_next_q) for L in layers] == ([0, 0, 1, 0, 1, 0] if on else [0] * 6)
     torch.testing.assert_close(outs[True], outs[False], rtol=2e-5, atol=2e-6)
 
