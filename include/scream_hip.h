@@ -129,6 +129,25 @@ int scream_gemm_qkv_split_f32(const float* A, int64_t lda, const void* W_packed,
                               float* kv_partial, int32_t layout, int32_t split, int32_t a_exp, int32_t w_exp,
                               int32_t k_exp, int32_t v_exp, void* stream);
 
+/* ---- The same fused q/k/v projection (A2 + the A3 reduce) as a RING kernel (scream_amd/csrc/proj_ring.hip, round 4; fp16 splits,
+ * fragment-major x in and Q' out): one wave per SIMD owns 64 rows and keeps their operand planes in registers for all of
+ * q | k | v, the weights stream chunk by chunk (32 output columns over K = 256 = one 32 KiB stage) through a ring of LDS stages,
+ * and every chunk's epilogue -- elu + 1 and the stores of a query chunk, or K' = elu(k) + 1, the operand split and K'^T V of a
+ * head -- runs in the shadow of the NEXT chunk's matrix instructions.  Same arithmetic per product and the same outputs as
+ * scream_gemm_qkv_split_f32 with SCREAM_LAYOUT_A_FRAG | SCREAM_LAYOUT_C_FRAG (Q' and the kv_partial array scream_kv_finalize_x3
+ * sums; the partial of a 128-row tile is added up from two 64-row halves instead of four 32-row quarters, so the two kernels
+ * agree to fp32 rounding, not bit for bit).  The weight matrix W [N, 256] (row order of scream_gemm_qkv_f32 above: q | per
+ * layer k 0-3 | v 0-3 | k 4-7 | v 4-7; n_q = 256 with N = 768, or n_q = 0 with N = 512 L) is packed once by scream_pack_proj
+ * into scream_proj_image_bytes(N, split) bytes: [N / 32 stages][split planes][16 fragments][64 lanes][8] fp16, in the order the
+ * kernel consumes them (query chunks 0 .. 7, then per layer and head K_h, V_h).  M % 128 == 0; exponents as for
+ * scream_gemm_qkv_split_f32 (a_exp, w_exp of the product; k_exp, v_exp of K' and V in the reduction). */
+int64_t scream_proj_image_bytes(int32_t N, int32_t split);
+int scream_pack_proj(const float* W, int32_t N, int32_t n_q, int32_t split, int32_t w_exp, void* proj_image, void* stream);
+int scream_proj_qkv_f32(const float* x, const void* proj_image, float* Q, int64_t M, int32_t N, int32_t n_q,
+                        const int32_t* tile_cloud, const int32_t* cloud_row0, const int32_t* cloud_len,
+                        int64_t row_base, float* kv_partial, int32_t split, int32_t a_exp, int32_t w_exp, int32_t k_exp,
+                        int32_t v_exp, void* stream);
+
 /* ---- A3 (apply) + A4 as ONE launch: everything of an MHAttention block that is local to a row,
  *     att = ((Q' . KV) * Z) * S;  m1 = LayerNorm1(att . Wm^T + x);  y = LayerNorm2(x + W2 . relu(W1 . m1))
  * Replaces models/transformer.py:41-42,83-88, i.e. scream_attn_apply + scream_gemm_split_f32(merge, EPI_RES_LN) +
@@ -235,6 +254,9 @@ typedef struct {
     int32_t e_k, e_v; /* of K' = elu(k) + 1 and of V in the projection's K^T V epilogue */
     scream_tail_exps_t tail_exps;
     int32_t tail_next_q; /* the tail image carries the NEXT layer's query projection (scream_pack_tail, Wq_next) */
+    /* fused-tail models on the fp16 splits only; may be NULL.  scream_pack_proj image of wqkv (exponent e_wqkv): the q/k/v
+     * projection of a self layer then runs on scream_proj_qkv_f32 and ignores wqkv. */
+    const void* proj;
 } scream_layer_t;
 
 typedef struct {
@@ -263,6 +285,9 @@ typedef struct {
      * cross layers' wkv / e_wkv. */
     const float* wkv_cross;
     int32_t e_wkv_cross, e_k_cross, e_v_cross; /* e_k / e_v: the smallest over the cross layers */
+    /* may be NULL: scream_pack_proj image of the same stacked matrix (n_q = 0, exponent e_wkv_cross): the batched target-side
+     * projection then runs on scream_proj_qkv_f32 (wkv_cross may then be NULL) */
+    const void* proj_cross;
 } scream_model_t;
 
 typedef struct {

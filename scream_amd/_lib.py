@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SCREAM_LIB=<path>: load that build instead (A/B runs of two builds on the same GPU box; never built automatically)
 LIB_PATH = os.environ.get("SCREAM_LIB") or os.path.join(_HERE, "libscream_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -31,7 +31,7 @@ class TailExpsT(C.Structure):
 class LayerT(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("wqkv", "wq", "wkv", "wm", "w1", "w2", "g1", "b1", "g2", "b2", "tail")] +
                 [(n, C.c_int32) for n in ("e_xq", "e_xkv", "e_wqkv", "e_wq", "e_wkv", "e_wm_g", "e_w1_g", "e_w2_g", "e_k", "e_v")] +
-                [("tail_exps", TailExpsT), ("tail_next_q", C.c_int32)])
+                [("tail_exps", TailExpsT), ("tail_next_q", C.c_int32), ("proj", C.c_void_p)])
 
 
 class ModelT(C.Structure):
@@ -41,7 +41,8 @@ class ModelT(C.Structure):
                 ("c2_w", C.c_void_p), ("c2_b", C.c_void_p), ("c4_w", C.c_void_p), ("c4_b", C.c_void_p),
                 ("stem_tgt_layers_host", C.POINTER(LayerT)), ("gemm_split", C.c_int32),
                 ("e_c0x", C.c_int32), ("e_c0w", C.c_int32), ("e_c2x", C.c_int32), ("e_c2w", C.c_int32),
-                ("wkv_cross", C.c_void_p), ("e_wkv_cross", C.c_int32), ("e_k_cross", C.c_int32), ("e_v_cross", C.c_int32)]
+                ("wkv_cross", C.c_void_p), ("e_wkv_cross", C.c_int32), ("e_k_cross", C.c_int32), ("e_v_cross", C.c_int32),
+                ("proj_cross", C.c_void_p)]
 
 
 class BatchT(C.Structure):
@@ -61,6 +62,9 @@ SIGNATURES = {
     "scream_pack_w_split": (C.c_int, [V, I32, I32, I32, I32, V, V]),
     "scream_gemm_split_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, I32, V, V, I64, V, V, I32, I32, I32, I32, V]),
     "scream_gemm_qkv_split_f32": (C.c_int, [V, I64, V, V, I64, I64, I32, I32, I32, V, V, V, I64, V, I32, I32, I32, I32, I32, I32, V]),
+    "scream_proj_image_bytes": (C.c_int64, [I32, I32]),
+    "scream_pack_proj": (C.c_int, [V, I32, I32, I32, I32, V, V]),
+    "scream_proj_qkv_f32": (C.c_int, [V, V, V, I64, I32, I32, V, V, V, I64, V, I32, I32, I32, I32, I32, V]),
     "scream_tail_image_bytes": (C.c_int64, [I32, I32]),
     "scream_kv_image_bytes": (C.c_int64, []),
     "scream_pack_tail": (C.c_int, [V, V, V, V, I32, C.POINTER(TailExpsT), V, V]),

@@ -17,6 +17,9 @@ ARCH = "gfx950"
 SOURCES = {
     "gemm_f32.hip": [],
     "gemm_split.hip": [],
+    # the MFMA results of this kernel are consumed by vector instructions (every chunk's epilogue rides under the next chunk's
+    # matrix instructions) while its row operand planes fill the whole AGPR file: accumulators in VGPRs, no moves between the files
+    "proj_ring.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     # several code instances of the same arithmetic (an attention apply in the open / riding under another stage) must round
     # identically, whatever hipcc makes of each: no fma contraction in this file
     "tail_split.hip": ["-ffp-contract=off"],

@@ -64,13 +64,26 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 
 // elu(x) + 1 (models/transformer.py:7-8: the feature map of the linear attention) = x + 1 for x > 0, exp(x) otherwise.  The
 // exponential runs on the hardware's exp2 (v_exp_f32, 1 ulp) with the rounding of x * log2(e) -- product and constant -- carried
-// into a first-order correction, exp2(hi) (1 + lo ln 2): within 2 ulp of exp(x), 6 vector instructions where expf() spends 14 on
+// into a first-order correction, exp2(hi) (1 + lo ln 2): within 2 ulp of exp(x), where expf() spends 14 vector instructions on
 // range handling that an argument <= 0 never needs (2 x 10^9 of these per 32-pair step, in epilogues no MFMA hides).
-__device__ __forceinline__ float elu1(float x) {
-    const float L2E = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f, LN2 = 0.693147182464599609375f;
-    const float hi = x * L2E;
-    const float lo = __builtin_fmaf(x, L2E_LO, __builtin_fmaf(x, L2E, -hi));
-    const float r = __builtin_amdgcn_exp2f(hi);
+// Round 4: no compare / select.  exp2's result is CLAMPED to [0, 1] (an output modifier of the instruction: free), so the
+// exponential branch is exact for x <= 0 and ~1 for x > 0, and since e^x >= 1 + x everywhere, elu(x) + 1 = max(1 + x, that):
+// eight instructions instead of ten (at the socket power cap every vector instruction of an epilogue is paid in time).
+// elu1s(t, c): elu(t c) + 1 for an accumulator t in units of 1 / c, c an exact power of two: the constants carry c (a power of
+// two commutes with every rounding), so the scaling multiply in front of the epilogue disappears -- bit for bit elu1(t * c).
+// Valid for |x| < 2^126 (beyond that x log2(e) overflows and 0 * inf appears).
+struct Elu1Consts {
+    float c, cl2e, cl2e_lo;  // c, c * log2(e) rounded to fp32, c * (log2(e) - that)
+};
+static inline Elu1Consts elu1_consts(float c) { return Elu1Consts{c, c * 1.44269502162933349609375f, c * 1.925963033500011e-08f}; }
+__device__ __forceinline__ float elu1s(float t, const Elu1Consts& k) {
+    const float LN2 = 0.693147182464599609375f;
+    const float hi = t * k.cl2e;
+    const float lo = __builtin_fmaf(t, k.cl2e_lo, __builtin_fmaf(t, k.cl2e, -hi));
+    const float r = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(hi), 0.0f, 1.0f);  // folds into v_exp_f32 ... clamp
     const float e = __builtin_fmaf(r, lo * LN2, r);
-    return x > 0.f ? x + 1.0f : e;  // (x > 0: e may be inf or nan -- never selected)
+    return fmaxf(__builtin_fmaf(t, k.c, 1.0f), e);
+}
+__device__ __forceinline__ float elu1(float x) {
+    return elu1s(x, Elu1Consts{1.0f, 1.44269502162933349609375f, 1.925963033500011e-08f});
 }

@@ -216,8 +216,8 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
 
 }  // namespace
 
-extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi15"; }
-extern "C" int scream_abi_version(void) { return 15; }
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi16"; }
+extern "C" int scream_abi_version(void) { return 16; }
 
 extern "C" void* scream_trace_create(int32_t capacity) {
     if (capacity <= 0) return nullptr;

@@ -33,6 +33,12 @@
 
 #include "ring.h"
 
+#ifndef P_PF
+#define P_PF 2  // register sets of weight fragments: fragments are read P_PF - 1 MFMA groups ahead (a third set does not fit: 512 registers)
+#endif
+#ifndef P_LB
+#define P_LB 2  // x segments per load batch at a tile boundary (two batches in flight)
+#endif
 #ifndef P_ABLATE
 #define P_ABLATE 0  // tuning aid (tools/proj_ablate.py): 1 no rides (epilogues dropped), 2 no MFMA, 4 no LDS fragment reads, 8 no W DMA after the first two stages, 16 no x prefetch
 #endif
@@ -57,7 +63,8 @@ struct ProjArgs {
     const int32_t* cloud_row0;
     const int32_t* cloud_len;
     int64_t row_base;
-    float a_scale, c_scale, kv_sk, kv_cv, kv_inv;  // 2^a_exp; 2^-(a_exp + w_exp); 2^k_exp; c_scale 2^v_exp; 2^-(k_exp + v_exp)
+    float a_scale, kv_sk, kv_cv, kv_inv;  // 2^a_exp; 2^k_exp; 2^(v_exp - a_exp - w_exp); 2^-(k_exp + v_exp)
+    Elu1Consts ec;                         // of c = 2^-(a_exp + w_exp): accumulator -> q, k (common.h: elu1s)
 };
 
 template <class SP>
@@ -67,8 +74,6 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
     constexpr int STAGE = stage_bytes<SP>();
     constexpr int PIECES = wave_pieces<SP>();   // LDS-DMA weight pieces per wave and stage
     constexpr int INFLIGHT = PIECES + 1;        // + the x prefetch touch: what a ring wait leaves in flight
-    constexpr int ND = 2;                       // MFMA groups of a stage deferred across the barrier (tail_split.hip)
-    constexpr int NG = 16 - ND;
     constexpr int NV = 6;                       // ride slots behind every MFMA
     __shared__ __attribute__((aligned(16))) char smem[T_SLOTS * STAGE + P_SLAB_BYTES + P_PF_BYTES];  // the ONLY LDS object
     float* slabs = reinterpret_cast<float*>(smem + T_SLOTS * STAGE);
@@ -133,28 +138,48 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
         }
         part_tile = pa.kv_partial + t128 * SCREAM_NHEAD * P_KV_ELEMS;
         qg = pa.Q + row0 * SCREAM_D_MODEL + lane * 4;
-        // one row group at a time: 32 loads (128 registers) in flight, then their split -- the other group's loads would not fit
-        // beside the pending accumulators
+        // the wave's 64 rows, P_LB segments of one row group (4 P_LB loads, 16 P_LB registers) at a time, two batches in flight:
+        // the next batch is requested before the previous one is split (the whole tile at once would not fit beside the
+        // pending accumulators and the K' planes)
+        constexpr int LB = P_LB, NB = 16 / LB;  // batch b: row group b / (NB / 2), segments LB (b % (NB / 2)) .. + LB - 1
+        f32x4 raw[2][LB][4];
+        auto request = [&](int b) __attribute__((always_inline)) {
+            const int rg = b / (NB / 2), blk0 = LB * (b % (NB / 2));
 #pragma unroll
-        for (int rg = 0; rg < 2; ++rg) {
-            f32x4 raw[8][4];
+            for (int k = 0; k < LB; ++k)
 #pragma unroll
-            for (int blk = 0; blk < 8; ++blk)
+                for (int a = 0; a < 4; ++a)
+                    raw[b & 1][k][a] = *reinterpret_cast<const f32x4*>(g + rg * 8192 + ((blk0 + k) * 4 + a) * 256);
+        };
+        request(0);
 #pragma unroll
-                for (int a = 0; a < 4; ++a) raw[blk][a] = *reinterpret_cast<const f32x4*>(g + rg * 8192 + (blk * 4 + a) * 256);
+        for (int b = 0; b < NB; ++b) {
+            const int rg = b / (NB / 2), blk0 = LB * (b % (NB / 2));
+            __builtin_amdgcn_sched_barrier(0);
+            if (b + 1 < NB) request(b + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int blk = 0; blk < 8; ++blk)
+            for (int k = 0; k < LB; ++k)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) split8<SP>(raw[blk][2 * s2] * pa.a_scale, raw[blk][2 * s2 + 1] * pa.a_scale, xp[rg][2 * blk + s2]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int s2 = 0; s2 < 2; ++s2)
+                {
+                    V tmp[NP];
+                    split8<SP>(raw[b & 1][k][2 * s2] * pa.a_scale, raw[b & 1][k][2 * s2 + 1] * pa.a_scale, tmp);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        // the planes LIVE in accumulation registers (the MFMA reads its A / B operand from either file): 256 of them,
+                        // the whole AGPR file -- left to itself hipcc keeps them VGPR-class and moves each one back before every use
+                        asm volatile("" : "+a"(tmp[p]));
+                        xp[rg][2 * (blk0 + k) + s2][p] = tmp[p];
+                    }
+                }
         }
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- pipeline state: the accumulators of a stage are consumed by the ride of the next one -----------------------------------
     f32x16 acc[2][2];       // [stage parity][row group]
-    V wfd[ND][NP];          // weight fragments of a stage's deferred groups
-    f16x8 kp[2][2][2];      // K' planes [row group][16-row step][plane]: A operand of K'^T V (the apply runs on fp16 x 2 for every SP)
+    f16x8 kp[2][2][2];      // K' planes [row group][16-row step][plane]: A operand of K'^T V (the reduction runs on fp16 x 2 for every SP)
     f32x16 kv;              // K'^T V of the wave's 64 rows: lane = v, registers = d
     float ks = 0.f;         // Ksum[d = r] over the wave's rows
     float* q_pend = nullptr;     // where the pending query chunk goes (its tile's qg + chunk offset)
@@ -164,7 +189,7 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
 
     // one MFMA group: 16-deep step g of both row groups against the same weight fragment
     // KIND 0: acc^T += W . x^T (lane = row, registers = features); KIND 1: acc += x . W^T (lane = feature, registers = rows)
-    auto group = [&](auto kind, f32x16 (&a)[2], const V (&w)[NP], int g, bool zero, bool sched) __attribute__((always_inline)) {
+    auto group = [&](auto kind, f32x16 (&a)[2], const V (&w)[NP], int g, bool zero) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind)::value;
         f32x16 z;
 #pragma unroll
@@ -179,7 +204,7 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
             if (KIND == 0) SP::products(a[rg], w, xp[rg][g], zero ? z : a[rg]);
             else SP::products(a[rg], xp[rg][g], w, zero ? z : a[rg]);
         }
-        if (!sched || (P_ABLATE & 2)) return;
+        if (P_ABLATE & 2) return;
         // first MFMA, then the prefetch reads of the next fragments (one per plane), then the other MFMAs with NV ride slots each
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
@@ -192,26 +217,24 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // One ring stage.  flush(): the deferred groups of the previous stage (they complete the accumulators the ride consumes);
-    // ride(g): the previous chunk's epilogue, cut into per-group pieces; stores only in groups <= 8, weight pieces from group 9 on.
-    auto stage = [&](auto kind, f32x16 (&a)[2], auto flush, auto ride) __attribute__((always_inline)) {
+    // One ring stage: 16 groups = one 32-column chunk of W over K = 256 against the wave's 64 rows.  ride(g): the previous
+    // chunk's epilogue, cut into per-group pieces; its stores only in groups <= 8, this stage's weight pieces from group 9 on.
+    auto stage = [&](auto kind, f32x16 (&a)[2], auto ride) __attribute__((always_inline)) {
         ring_barrier<INFLIGHT>();
         __builtin_amdgcn_sched_barrier(0);
         const char* wb = smem + (q % T_SLOTS) * STAGE + lane * 16;
-        V wf[T_PF][NP];
+        V wf[P_PF][NP];
 #pragma unroll
-        for (int g0 = 0; g0 < T_PF - 1; ++g0)
+        for (int g0 = 0; g0 < P_PF - 1; ++g0)
 #pragma unroll
             for (int p = 0; p < NP; ++p) wf[g0][p] = ld_frag<V>(wb + (p * 16 + g0) * 1024);
-        flush();
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + T_PF - 1 < 16) {
+        for (int g = 0; g < 16; ++g) {
+            if (g + P_PF - 1 < 16) {
 #pragma unroll
-                for (int p = 0; p < NP; ++p)
-                    (g + T_PF - 1 >= NG ? wfd[g + T_PF - 1 - NG][p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag<V>(wb + (p * 16 + g + T_PF - 1) * 1024);
+                for (int p = 0; p < NP; ++p) wf[(g + P_PF - 1) % P_PF][p] = ld_frag<V>(wb + (p * 16 + g + P_PF - 1) * 1024);
             }
-            if (g >= 9) {  // nine requests in five groups: 2 2 2 2 1 (PIECES weight pieces, then the x prefetch touch)
+            if (g >= 9 && g < 14) {  // nine requests in five groups: 2 2 2 2 1 (PIECES weight pieces, then the x prefetch touch)
 #pragma unroll
                 for (int u = (g - 9) * 2; u < (g - 8) * 2; ++u) {
                     if (u < PIECES) dma_piece(q + 2, u);
@@ -219,30 +242,22 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
                 }
             }
             if (!(P_ABLATE & 1)) ride(g);
-            group(kind, a, wf[g % T_PF], g, g == 0, true);
+            group(kind, a, wf[g % P_PF], g, g == 0);
         }
         ++q;
     };
     static_assert(wave_pieces<SP>() <= 8, "the request schedule of a stage holds nine requests");
     constexpr std::integral_constant<int, 0> kindQ{};
     constexpr std::integral_constant<int, 1> kindKV{};
-    auto flush_into = [&](auto kind, f32x16 (&a)[2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < ND; ++i) group(kind, a, wfd[i], NG + i, false, false);
-    };
 
     // ---- rides --------------------------------------------------------------------------------------------------------------
-    // Q' chunk = elu(q) + 1, fragment-major: piece a of an accumulator tile is one 1 KiB wave store (tail_split.hip: store_chunk)
-    f32x4 oq[2][4];
-    auto ride_q = [&](const f32x16 (&t)[2], int g) __attribute__((always_inline)) {
+    // Q' chunk = elu(q) + 1 in place, fragment-major: piece a of an accumulator tile is one 1 KiB wave store (tail_split.hip: store_chunk)
+    auto ride_q = [&](f32x16 (&t)[2], int g) __attribute__((always_inline)) {
         if (g < 8) {
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int i = 2 * g + e;
-                    oq[rg][i >> 2][i & 3] = elu1(t[rg][i] * pa.c_scale);
-                }
+                for (int e = 0; e < 2; ++e) t[rg][2 * g + e] = elu1s(t[rg][2 * g + e], pa.ec);
         }
         if (g == 8) {
             __builtin_amdgcn_sched_barrier(0);
@@ -250,27 +265,27 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
 #pragma unroll
                 for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) *reinterpret_cast<f32x4*>(q_pend + rg * 8192 + a * 256) = oq[rg][a];
+                    for (int a = 0; a < 4; ++a) {
+                        const f32x4 o = {t[rg][4 * a], t[rg][4 * a + 1], t[rg][4 * a + 2], t[rg][4 * a + 3]};
+                        *reinterpret_cast<f32x4*>(q_pend + rg * 8192 + a * 256) = o;
+                    }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // K' = elu(k) + 1 with the padding rows zeroed, its row sum and its two fp16 planes: four elements per group
-    auto ride_k = [&](const f32x16 (&t)[2], int valid, int g) __attribute__((always_inline)) {
+    // K' = elu(k) + 1 with the padding rows zeroed, its row sum and its two fp16 planes: one register of both row groups per group.
+    // MASK (compile time; wave-uniform per tile): only a cloud's last tile has padding rows -- everywhere else the compare and
+    // select per element (two of a dozen vector instructions; at the socket power cap every one of them is paid in time) are left out
+    auto ride_k = [&](auto mask, const f32x16 (&t)[2], int valid, int g) __attribute__((always_inline)) {
         if (g == 0) ks = 0.f;
-        if (g < 8) {
 #pragma unroll
-            for (int rg = 0; rg < 2; ++rg)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int i = 2 * g + e;
-                    float a = elu1(t[rg][i] * pa.c_scale);
-                    if (mfma32_row(i, half) + 32 * rg >= valid) a = 0.f;
-                    ks += a;
-                    SplitH2::split1(a * pa.kv_sk, i & 7, kp[rg][i >> 3]);
-                }
+        for (int rg = 0; rg < 2; ++rg) {
+            float a = elu1s(t[rg][g], pa.ec);
+            if (decltype(mask)::value && (g & 3) + 8 * (g >> 2) + 32 * rg >= valid) a = 0.f;  // row mfma32_row(g, half) + 32 rg of the wave's 64 (valid carries the half)
+            ks += a;
+            SplitH2::split1(a * pa.kv_sk, g & 7, kp[rg][g >> 3]);
         }
-        if (g == 8) ks += __shfl_xor(ks, 32);
+        if (g == 15) ks += __shfl_xor(ks, 32);
     };
     // V's planes, the 12 MFMAs of K'^T V over the wave's 64 rows, the wave's tile into its LDS slab
     f16x8 vp[2][2];  // [row group][plane] of the 16-row step being made
@@ -312,7 +327,6 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
 
     // ---- the block's units ----------------------------------------------------------------------------------------------------
     int prev = 0;  // what the previous unit left pending in acc[1]: 0 nothing, 1 a query chunk, 2 a value chunk (+ its head's K' planes)
-    auto none = [&]() __attribute__((always_inline)) {};
     auto no_ride = [&](int) __attribute__((always_inline)) {};
 #define LAMBDA(...) [&](__VA_ARGS__) __attribute__((always_inline))
     for (int64_t u = u_lo; u < u_hi; ++u) {
@@ -322,26 +336,33 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
         if (uu < nq2) {
             // ---- two query chunks 2 uu, 2 uu + 1
             float* q_even = qg + (2 * uu) * 1024;
-            if (prev == 0) stage(kindQ, acc[0], none, no_ride);
-            else if (prev == 1) stage(kindQ, acc[0], LAMBDA() { flush_into(kindQ, acc[1]); }, LAMBDA(int g) { ride_q(acc[1], g); });
-            else stage(kindQ, acc[0], LAMBDA() { flush_into(kindKV, acc[1]); }, LAMBDA(int g) { ride_v(acc[1], g); });
+            if (prev == 0) stage(kindQ, acc[0], no_ride);
+            else if (prev == 1) stage(kindQ, acc[0], LAMBDA(int g) { ride_q(acc[1], g); });
+            else stage(kindQ, acc[0], LAMBDA(int g) { ride_v(acc[1], g); });
             const bool store_kv = prev == 2;
             q_pend = q_even;
             q_pend_ok = wave_ok;
-            if (store_kv) stage(kindQ, acc[1], LAMBDA() { flush_into(kindQ, acc[0]); }, LAMBDA(int g) { ride_kvstore(g); ride_q(acc[0], g); });
-            else stage(kindQ, acc[1], LAMBDA() { flush_into(kindQ, acc[0]); }, LAMBDA(int g) { ride_q(acc[0], g); });
+            if (store_kv) stage(kindQ, acc[1], LAMBDA(int g) { ride_kvstore(g); ride_q(acc[0], g); });
+            else stage(kindQ, acc[1], LAMBDA(int g) { ride_q(acc[0], g); });
             q_pend = q_even + 1024;
             prev = 1;
         } else {
             // ---- head h of layer l: K chunk, then V chunk
             const int p = uu - nq2, l = p >> 3, h = p & 7;
-            if (prev == 0) stage(kindKV, acc[0], none, no_ride);
-            else if (prev == 1) stage(kindKV, acc[0], LAMBDA() { flush_into(kindQ, acc[1]); }, LAMBDA(int g) { ride_q(acc[1], g); });
-            else stage(kindKV, acc[0], LAMBDA() { flush_into(kindKV, acc[1]); }, LAMBDA(int g) { ride_v(acc[1], g); });
+            if (prev == 0) stage(kindKV, acc[0], no_ride);
+            else if (prev == 1) stage(kindKV, acc[0], LAMBDA(int g) { ride_q(acc[1], g); });
+            else stage(kindKV, acc[0], LAMBDA(int g) { ride_v(acc[1], g); });
             const bool store_kv = prev == 2;
-            const int valid = valid0;
-            if (store_kv) stage(kindKV, acc[1], LAMBDA() { flush_into(kindKV, acc[0]); }, LAMBDA(int g) { ride_kvstore(g); ride_k(acc[0], valid, g); });
-            else stage(kindKV, acc[1], LAMBDA() { flush_into(kindKV, acc[0]); }, LAMBDA(int g) { ride_k(acc[0], valid, g); });
+            const int valid = valid0 - 4 * half;  // per lane: the compare below is then against a literal
+            constexpr std::integral_constant<bool, true> masked{};
+            constexpr std::integral_constant<bool, false> whole{};
+            if (valid0 < 64) {  // (idle waves: valid0 == 0)
+                if (store_kv) stage(kindKV, acc[1], LAMBDA(int g) { ride_kvstore(g); ride_k(masked, acc[0], valid, g); });
+                else stage(kindKV, acc[1], LAMBDA(int g) { ride_k(masked, acc[0], valid, g); });
+            } else {
+                if (store_kv) stage(kindKV, acc[1], LAMBDA(int g) { ride_kvstore(g); ride_k(whole, acc[0], valid, g); });
+                else stage(kindKV, acc[1], LAMBDA(int g) { ride_k(whole, acc[0], valid, g); });
+            }
             part_pend = part_tile + (int64_t)l * pa.kv_layer_stride + h * P_KV_ELEMS;
             part_pend_ok = wave_ok;
             prev = 2;
@@ -349,15 +370,11 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
     }
     // ---- the pipeline's end, in the open
     __builtin_amdgcn_sched_barrier(0);
-    if (prev == 1) {
-        flush_into(kindQ, acc[1]);
-        if (!(P_ABLATE & 1)) {
+    if (!(P_ABLATE & 1)) {
+        if (prev == 1) {
 #pragma unroll
             for (int g = 0; g < 9; ++g) ride_q(acc[1], g);
-        }
-    } else if (prev == 2) {
-        flush_into(kindKV, acc[1]);
-        if (!(P_ABLATE & 1)) {
+        } else if (prev == 2) {
             lds_only_barrier();  // every wave has read the previous head's slabs (the ride of the stage just finished)
 #pragma unroll
             for (int g = 0; g < 14; ++g) ride_v(acc[1], g);
@@ -456,7 +473,7 @@ extern "C" int scream_proj_qkv_f32(const float* x, const void* proj_image, float
     pa.cloud_len = cloud_len;
     pa.row_base = row_base;
     pa.a_scale = exp2i(a_exp);
-    pa.c_scale = exp2i(-a_exp - w_exp);
+    pa.ec = elu1_consts(exp2i(-a_exp - w_exp));
     pa.kv_sk = exp2i(k_exp);
     pa.kv_cv = exp2i(-a_exp - w_exp + v_exp);
     pa.kv_inv = exp2i(-k_exp - v_exp);

@@ -233,6 +233,56 @@ def gemm_qkv(A: torch.Tensor, W, n_q: int, tile_cloud, cloud_row0, cloud_len, ro
     return Q, part
 
 
+@dataclass
+class PackedProj:
+    """A q/k/v (n_q = 256, N = 768) or stacked key/value (n_q = 0, N = 512 L) weight matrix in the ring projection kernel's stage
+    image (scream_pack_proj): fp16 planes of W * 2^w_exp, one 32-column chunk over K = 256 per stage."""
+    data: torch.Tensor
+    split: int
+    w_exp: int
+    N: int
+    n_q: int
+    row_l1: Optional[torch.Tensor] = None
+
+    def data_ptr(self) -> int:
+        return self.data.data_ptr()
+
+
+def pack_proj(W: torch.Tensor, n_q: int, split: Optional[int] = None, w_exp: Optional[int] = None) -> PackedProj:
+    """[N,256] fp32 in the row order of gemm_qkv -> the stage image of proj_qkv (fp16 splits only)."""
+    split = SPLIT_H2 if split is None else split
+    W = W.detach().to(torch.float32).contiguous()
+    N, K = W.shape
+    assert K == D_MODEL
+    w_exp = scales.w_exp(W) if w_exp is None else int(w_exp)
+    nbytes = _lib.load().scream_proj_image_bytes(N, split)
+    if nbytes <= 0:
+        raise _lib.ScreamHipError("scream_proj_image_bytes(%d, %d) = %d" % (N, split, nbytes))
+    out = torch.empty(nbytes, device=W.device, dtype=torch.uint8)
+    check(_lib.load().scream_pack_proj(_p(W), N, n_q, split, w_exp, _p(out, torch.uint8), _stream()), "scream_pack_proj")
+    return PackedProj(out, split, w_exp, N, n_q, W.abs().sum(dim=1).cpu())
+
+
+def proj_qkv(x_frag: torch.Tensor, P: PackedProj, tile_cloud, cloud_row0, cloud_len, row_base: int,
+             a_exp: Optional[int] = None, k_exp: Optional[int] = None, v_exp: Optional[int] = None):
+    """The fused q/k/v projection on the ring kernel (scream_proj_qkv_f32): x and Q' fragment-major.  Returns (Q' or None,
+    kv_partial) like gemm_qkv."""
+    M = x_frag.shape[0]
+    Q = torch.empty(M, D_MODEL, device=x_frag.device, dtype=torch.float32) if P.n_q else None
+    L = (P.N - P.n_q) // 512
+    part = torch.empty((L, M // ROW_TILE, 8, KV_ELEMS) if L > 1 else (M // ROW_TILE, 8, KV_ELEMS), device=x_frag.device, dtype=torch.float32)
+    if a_exp is None or k_exp is None or v_exp is None:  # convenience defaults (a device sync): tests and tools only
+        amax = float(x_frag.abs().max().item())
+        rl = P.row_l1[P.n_q:].view(-1, 2, 128)
+        a_exp = scales.exp_for(amax) if a_exp is None else a_exp
+        k_exp = scales.exp_for(1.0 + amax * float(rl[:, 0].max())) if k_exp is None else k_exp
+        v_exp = scales.exp_for(amax * float(rl[:, 1].max())) if v_exp is None else v_exp
+    check(_lib.load().scream_proj_qkv_f32(_p(x_frag), P.data_ptr(), _p(Q), M, P.N, P.n_q, _p(tile_cloud, torch.int32),
+                                          _p(cloud_row0, torch.int32), _p(cloud_len, torch.int32), row_base, _p(part), P.split,
+                                          int(a_exp), P.w_exp, int(k_exp), int(v_exp), _stream()), "scream_proj_qkv_f32")
+    return Q, part
+
+
 def kv_finalize(part, cloud_row0, cloud_len, row_base: int, cloud_begin: int, n_kv: int, n_clouds: int) -> torch.Tensor:
     kv = torch.zeros(n_clouds, 8, KV_ELEMS, device=part.device, dtype=torch.float32)
     check(_lib.load().scream_kv_finalize(_p(part), _p(cloud_row0, torch.int32), _p(cloud_len, torch.int32), row_base,

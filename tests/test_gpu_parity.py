@@ -300,6 +300,73 @@ def test_fused_qkv_projection_and_kv_reduce_vs_oracle(kind):
     torch.testing.assert_close(kv2[1], kv[1], rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("split", ["h2", "h1"])
+def test_ring_projection_vs_oracle_and_vs_the_eight_wave_gemm(split):
+    """scream_proj_qkv_f32 (csrc/proj_ring.hip: 64 rows per wave, weights through the LDS ring, epilogues riding under the next
+    chunk's matrix instructions) against the oracle's intermediates (models/transformer.py:79-81,28-29,38-41) and against
+    scream_gemm_qkv_split_f32 on the same fragment-major input and exponents: Q' of real rows, K^T (V/S), Ksum per cloud; ragged
+    clouds with garbage in the padding rows, an odd number of 128-row tiles (two idle waves in the last 256-row tile), the
+    key/value-only form of two layers with a row base, and another cut of the rows into 256-row tiles."""
+    SPL = {"h2": ops.SPLIT_H2, "h1": ops.SPLIT_H1}[split]
+    sd = make_state_dict(9, 256, 1, 1)
+    rng = np.random.default_rng(2)
+    lens, row0, rows = [300, 129, 700], [0, 384, 640], 1408  # 11 tiles of 128 rows
+    x = torch.zeros(rows, 256)
+    xs = [torch.from_numpy(rng.normal(size=(n, 256)).astype(np.float32)) for n in lens]
+    for r0, xc in zip(row0, xs):
+        x[r0:r0 + xc.shape[0]] = xc
+    x[300:384] = 3.0
+    x[640 + 700:] = -2.5
+    q, k, v = (sd["stem.0.%s_proj.weight" % n] for n in "qkv")
+    W = torch.cat([q, k[:128], v[:128], k[128:], v[128:]], dim=0)
+    tile_cloud = dev(torch.tensor([0] * 3 + [1] * 2 + [2] * 6, dtype=torch.int32))
+    crow0, clen = dev(torch.tensor(row0, dtype=torch.int32)), dev(torch.tensor(lens, dtype=torch.int32))
+    xf = ops.act_layout(dev(x), True)
+    w_exp, a_exp = scales.w_exp(W), scales.exp_for(float(x.abs().max()))
+    P = ops.pack_proj(dev(W), 256, SPL, w_exp)
+    rl = P.row_l1[256:].view(-1, 2, 128)
+    k_exp, v_exp = scales.exp_for(1.0 + 6.0 * float(rl[:, 0].max())), scales.exp_for(6.0 * float(rl[:, 1].max()))
+    Qf, part = ops.proj_qkv(xf, P, tile_cloud, crow0, clen, 0, a_exp=a_exp, k_exp=k_exp, v_exp=v_exp)
+    Q = ops.act_layout(Qf, False).cpu()
+    kv = ops.kv_finalize(part, crow0, clen, 0, 0, 3, 3).cpu()
+    # the 8-wave GEMM on the same operands
+    Qg, partg = ops.gemm_qkv(xf, ops.pack_w(dev(W), SPL, w_exp), 256, tile_cloud, crow0, clen, 0, layout=ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG,
+                             a_exp=a_exp, k_exp=k_exp, v_exp=v_exp)
+    Qg = ops.act_layout(Qg, False).cpu()
+    kvg = ops.kv_finalize(partg, crow0, clen, 0, 0, 3, 3).cpu()
+    tol = dict(rtol=1e-5, atol=1e-5) if split == "h2" else dict(rtol=3e-3, atol=3e-3)
+    for ci, (r0, xc) in enumerate(zip(row0, xs)):
+        n = xc.shape[0]
+        assert torch.equal(Q[r0:r0 + n], Qg[r0:r0 + n]) or split == "h2" and (Q[r0:r0 + n] - Qg[r0:r0 + n]).abs().max() < 2e-6  # same products, another internal order
+        torch.testing.assert_close(kv[ci], kvg[ci], rtol=2e-5, atol=2e-5)
+        if split != "h2":
+            continue
+        want = {}
+        O.mh_attention(xc[None], xc[None], xc[None], sd, "stem.0.", want)
+        torch.testing.assert_close(Q[r0:r0 + n].reshape(n, 8, 32), want["Q"][0], **tol)
+        kvt = kv[ci, :, :1024].reshape(8, 32, 32)  # [h][v][d]
+        torch.testing.assert_close(kvt.permute(0, 2, 1), want["KV"][0], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(kv[ci, :, 1024:], want["Ksum"][0], rtol=1e-5, atol=1e-4)
+    # deterministic, and the same bits wherever a block's share of the stage sequence begins: rows [384, 1408) as their own launch
+    # (other tile boundaries: cloud 1 now starts a 256-row tile) reproduce the partials of those tiles
+    Qf2, part2 = ops.proj_qkv(xf, P, tile_cloud, crow0, clen, 0, a_exp=a_exp, k_exp=k_exp, v_exp=v_exp)
+    assert torch.equal(Qf2, Qf) and torch.equal(part2, part)
+    Qf3, part3 = ops.proj_qkv(xf[384:], P, tile_cloud, crow0, clen, 384, a_exp=a_exp, k_exp=k_exp, v_exp=v_exp)
+    assert torch.equal(Qf3, Qf[384:]) and torch.equal(part3, part[3:])
+    # key/value-only form of several layers (the cross stage's target side), with a row base
+    Wkv = torch.cat([W[256:], 2.0 * W[256:].flip(0)])
+    wk_exp = scales.w_exp(Wkv)
+    Pk = ops.pack_proj(dev(Wkv), 0, SPL, wk_exp)
+    _, partk = ops.proj_qkv(xf[384:], Pk, tile_cloud, crow0, clen, 384, a_exp=a_exp, k_exp=k_exp - 1, v_exp=v_exp - 1)
+    _, partkg = ops.gemm_qkv(xf[384:], ops.pack_w(dev(Wkv), SPL, wk_exp), 0, tile_cloud, crow0, clen, 384, layout=ops.LAYOUT_A_FRAG,
+                             a_exp=a_exp, k_exp=k_exp - 1, v_exp=v_exp - 1)
+    assert partk.shape == partkg.shape == (2, 8, 8, 1056)
+    for l in range(2):
+        a = ops.kv_finalize(partk[l], crow0, clen, 384, 1, 2, 3).cpu()
+        b = ops.kv_finalize(partkg[l], crow0, clen, 384, 1, 2, 3).cpu()
+        torch.testing.assert_close(a[1:], b[1:], rtol=2e-5 if split == "h2" else 1e-3, atol=2e-5 if split == "h2" else 1e-3)
+
+
 @pytest.mark.parametrize("split", ["h2", "x3"])
 def test_batched_key_value_projection_of_several_layers_equals_one_launch_per_layer(split):
     """scream_gemm_qkv_split_f32 with N = 512 L, n_q == 0 (the cross stage's target side: the target features are frozen after
