@@ -105,9 +105,13 @@ int gemm(const Ctx& c, const float* A, int64_t lda, const float* W, float* C, in
     return scream_gemm_f32(A, lda, W, C, ldc, M, N, K, epi, n_act, bias, res, D, g, b, c.st);
 }
 
-int gemm_qkv(const Ctx& c, const float* A, const float* W, float* Q, int64_t M, int N, int n_q, const scream_batch_t& b,
+// proj: the ring kernel's image of the same matrix (fused-tail models on an fp16 split; NULL: the 8-wave GEMM)
+int gemm_qkv(const Ctx& c, const float* A, const float* W, const void* proj, float* Q, int64_t M, int N, int n_q, const scream_batch_t& b,
              int64_t row_base, float* kvp, int a_exp, int w_exp, int k_exp, int v_exp) {
     Scope sc(c.tr, 5, M, N, D, c.st);
+    if (proj && c.frag && (c.split == SCREAM_SPLIT_H2 || c.split == SCREAM_SPLIT_H1))
+        return scream_proj_qkv_f32(A, proj, Q, M, N, n_q, b.tile_cloud, b.cloud_row0, b.cloud_len, row_base, kvp, c.split, a_exp, w_exp,
+                                   k_exp, v_exp, c.st);
     if (c.split)
         return scream_gemm_qkv_split_f32(A, D, W, Q, D, M, N, D, n_q, b.tile_cloud, b.cloud_row0, b.cloud_len, row_base, kvp,
                                          c.frag ? (SCREAM_LAYOUT_A_FRAG | (n_q ? SCREAM_LAYOUT_C_FRAG : 0)) : 0, c.split, a_exp,
@@ -138,7 +142,7 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
     const float* xr = x + row0 * D;
     float* qr = w.q + row0 * D;
     float* kvp = w.kvp + row0 / SCREAM_ROW_TILE * SCREAM_NHEAD * KV_ELEMS;
-    TRY(gemm_qkv(c, xr, L.wqkv, qr, rows, 3 * D, D, b, row0, kvp, L.e_xq, L.e_wqkv, L.e_k, L.e_v));
+    TRY(gemm_qkv(c, xr, L.wqkv, L.proj, qr, rows, 3 * D, D, b, row0, kvp, L.e_xq, L.e_wqkv, L.e_k, L.e_v));
     if (c.frag) {  // apply + merge + norm1 + FFN + norm2 in one launch
         {
             Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
@@ -168,7 +172,7 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
 int cross_kv_all(const Ctx& c, const scream_model_t& m, const scream_batch_t& b, const Workspace& w, const float* x_tgt) {
     const int64_t rs = b.rows_src, rt = b.rows_total - b.rows_src;
     const scream_layer_t& L0 = m.layers_host[m.n_self + 1];  // every cross layer sees the same target features: one e_xkv
-    TRY(gemm_qkv(c, x_tgt, m.wkv_cross, nullptr, rt, 2 * D * m.n_cross, 0, b, rs, w.kvp_cross, L0.e_xkv, m.e_wkv_cross, m.e_k_cross,
+    TRY(gemm_qkv(c, x_tgt, m.wkv_cross, m.proj_cross, nullptr, rt, 2 * D * m.n_cross, 0, b, rs, w.kvp_cross, L0.e_xkv, m.e_wkv_cross, m.e_k_cross,
                  m.e_v_cross));
     Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
     // images are indexed by ABSOLUTE cloud (targets are clouds n_pairs .. 2 n_pairs - 1): layer l's block starts n_pairs images early
@@ -193,7 +197,7 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
         return scream_layer_tail_f32(w.q, kvimg_layer, b.tile_cloud, 0, b.cloud_len + b.n_pairs, x_src, L.tail, L.g1, L.b1, L.g2,
                                      L.b2, y, nullptr, rs, c.split, &L.tail_exps, c.st);
     }
-    TRY(gemm_qkv(c, x_tgt, L.wkv, nullptr, rt, 2 * D, 0, b, rs, w.kvp, L.e_xkv, L.e_wkv, L.e_k, L.e_v));
+    TRY(gemm_qkv(c, x_tgt, L.wkv, nullptr, nullptr, rt, 2 * D, 0, b, rs, w.kvp, L.e_xkv, L.e_wkv, L.e_k, L.e_v));
     if (c.frag) {
         {
             Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);

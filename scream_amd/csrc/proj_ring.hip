@@ -164,7 +164,8 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
                 for (int s2 = 0; s2 < 2; ++s2)
                 {
                     V tmp[NP];
-                    split8<SP>(raw[b & 1][k][2 * s2] * pa.a_scale, raw[b & 1][k][2 * s2 + 1] * pa.a_scale, tmp);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) SP::split1s(raw[b & 1][k][2 * s2 + (j >> 2)][j & 3], pa.a_scale, j, tmp);
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
                         // the planes LIVE in accumulation registers (the MFMA reads its A / B operand from either file): 256 of them,
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
             float a = elu1s(t[rg][g], pa.ec);
             if (decltype(mask)::value && (g & 3) + 8 * (g >> 2) + 32 * rg >= valid) a = 0.f;  // row mfma32_row(g, half) + 32 rg of the wave's 64 (valid carries the half)
             ks += a;
-            SplitH2::split1(a * pa.kv_sk, g & 7, kp[rg][g >> 3]);
+            SplitH2::split1s(a, pa.kv_sk, g & 7, kp[rg][g >> 3]);
         }
         if (g == 15) ks += __shfl_xor(ks, 32);
     };
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int i = 8 * s2 + 2 * (g & 3) + e;
-                    SplitH2::split1(t[rg][i] * pa.kv_cv, i & 7, vp[rg]);
+                    SplitH2::split1s(t[rg][i], pa.kv_cv, i & 7, vp[rg]);
                 }
             if ((g & 3) == 3) {
                 f32x16 z;

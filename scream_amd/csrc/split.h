@@ -70,6 +70,16 @@ struct SplitH2 {
         p[0][i] = a;
         p[1][i] = (_Float16)(x - (float)a);       // the residual is exact in fp32
     }
+    // the same planes of x * s for an exact power of two s, written so that each plane is ONE instruction (v_fma_mix{lo,hi}_f16:
+    // an fp32 fma whose result is rounded to fp16 straight into one half of the destination, its addend read as fp16): the product
+    // x s is exact, so fp16(fma(x, s, 0)) and fp16(fma(x, s, -x0)) are bit for bit split1(x * s) -- two instructions per element
+    // where multiply, convert, convert back, subtract, convert and pack are three and a half (proj_ring.hip: every vector
+    // instruction of an epilogue is paid in time at the socket power cap)
+    static __device__ __forceinline__ void split1s(float x, float s, int i, vec (&p)[2]) {
+        const _Float16 a = (_Float16)__builtin_fmaf(x, s, 0.0f);
+        p[0][i] = a;
+        p[1][i] = (_Float16)__builtin_fmaf(x, s, -(float)a);
+    }
     static __device__ __forceinline__ f32x16 mfma(vec a, vec b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     template <bool MIRROR = false>
     static __device__ __forceinline__ void products(f32x16& acc, const vec (&x)[2], const vec (&y)[2], const f32x16& c0) {
@@ -90,6 +100,7 @@ struct SplitH1 {
     static constexpr bool SCALED = true;
     typedef f16x8 vec;
     static __device__ __forceinline__ void split1(float x, int i, vec (&p)[1]) { p[0][i] = (_Float16)x; }
+    static __device__ __forceinline__ void split1s(float x, float s, int i, vec (&p)[1]) { p[0][i] = (_Float16)__builtin_fmaf(x, s, 0.0f); }
     static __device__ __forceinline__ f32x16 mfma(vec a, vec b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     template <bool MIRROR = false>
     static __device__ __forceinline__ void products(f32x16& acc, const vec (&x)[1], const vec (&y)[1], const f32x16& c0) {

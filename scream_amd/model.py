@@ -118,11 +118,17 @@ class PointTransformer(nn.Module):
     # SCREAM_FUSE_NEXT_Q=0 keeps the separate projection launches
     fuse_next_q = os.environ.get("SCREAM_FUSE_NEXT_Q", "1") != "0"
 
+    # fused tail on an fp16 split only: the q/k/v projections (and the batched target-side key/value projection) on the RING kernel
+    # (csrc/proj_ring.hip, round 4: 64 rows per wave, epilogues riding under the next chunk's matrix instructions, no partial last
+    # round) instead of the 8-wave GEMM; SCREAM_RING_PROJ=0 keeps the GEMM (same arithmetic per product; K^T V partials summed
+    # from two halves instead of four quarters)
+    ring_proj = os.environ.get("SCREAM_RING_PROJ", "1") != "0"
+
     def _fused_cfg(self, split) -> bool:
         return bool(split and self.fused_tail)
 
     def _signature(self):
-        return (self.fused_tail, self.batched_cross_kv, self.fuse_next_q) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.fused_tail, self.batched_cross_kv, self.fuse_next_q, self.ring_proj) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _layer_inputs(self):
         """(in_q, in_kv) per layer of _layer_modules() [+ per layer of _stem_tgt_modules()] and the coordinate MLP's input:
@@ -213,6 +219,11 @@ class PointTransformer(nn.Module):
             k, v = m.k_proj.weight, m.v_proj.weight
             wkv = torch.cat([k[:128], v[:128], k[128:], v[128:]], dim=0)
             L.wqkv, L.e_wqkv = dev_mat(torch.cat([m.q_proj.weight, wkv], dim=0))
+            L.proj = None
+            if fp16_split and self.fused_tail and self.ring_proj:  # the same matrix as the ring kernel's stage image, same exponent
+                pp = ops.pack_proj(torch.cat([m.q_proj.weight, wkv], dim=0).detach().to(device=dev, dtype=torch.float32), 256, split, L.e_wqkv)
+                keep.append(pp.data)
+                L.proj = pp.data_ptr()
             L.wq, L.e_wq = dev_mat(m.q_proj.weight)
             L.wkv, L.e_wkv = dev_mat(wkv)
             ex = scales.layer_exps(m, in_q, in_kv) if fp16_split else {}
@@ -251,13 +262,17 @@ class PointTransformer(nn.Module):
         (mt.c0_w, mt.e_c0w), mt.c0_b = dev_mat(c0w), dev_f32(self.coor_mlp[0].bias)
         (mt.c2_w, mt.e_c2w), mt.c2_b = dev_mat(c2w), dev_f32(self.coor_mlp[2].bias)
         mt.c4_w, mt.c4_b = dev_f32(self.coor_mlp[4].weight[:, :, 0]), dev_f32(self.coor_mlp[4].bias)
-        mt.wkv_cross = None
+        mt.wkv_cross, mt.proj_cross = None, None
         if self._fused_cfg(split) and self.batched_cross_kv and self.cross_layer_num > 0:
             # the cross layers' key/value projections of the (frozen) target features as ONE GEMM, models/pointnet.py:53-57
             cross = [m for i, m in enumerate(self.cross) if i % 2 == 1]
             stack = torch.cat([torch.cat([c.layer.k_proj.weight[:128], c.layer.v_proj.weight[:128], c.layer.k_proj.weight[128:],
                                           c.layer.v_proj.weight[128:]], dim=0) for c in cross], dim=0)
             mt.wkv_cross, mt.e_wkv_cross = dev_mat(stack)
+            if fp16_split and self.ring_proj:
+                pp = ops.pack_proj(stack.detach().to(device=dev, dtype=torch.float32), 0, split, mt.e_wkv_cross)
+                keep.append(pp.data)
+                mt.proj_cross = pp.data_ptr()
             cross_L = [layers[self.self_layer_num + 2 * j + 1] for j in range(self.cross_layer_num)]
             mt.e_k_cross, mt.e_v_cross = min(L.e_k for L in cross_L), min(L.e_v for L in cross_L)  # one launch: the tightest
         if fp16_split:  # coor_mlp (models/pointnet.py:27-33): LayerNorm2 output -> Conv1d + bias, relu -> Conv1d
