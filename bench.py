@@ -50,13 +50,16 @@ sys.path.insert(0, REPO)
 PAIRS_PER_GPU = 32
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_16BIT_DENSE_TFLOPS = 2500.0  # same table, bf16 and fp16; the split kernels spend 3 (fp16 x 2) or 6 (bf16 x 3) MFMAs per fp32 product
+PEAK_HBM_GBPS = 8000.0  # same table: HBM3E 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
+PEAK_FP32_VALU_TFLOPS = 78.6  # unpacked fp32 fma: 64 lanes x 2 flop per 4 cycles per SIMD, 1024 SIMDs, 2.4 GHz (the vector peak of 157.3 counts v_pk_fma_f32, which issues at half rate here)
+TR_EMBED, TR_KV_REDUCE = 100, 101  # scream_trace record kinds (include/scream_hip.h)
 MFMAS_PER_PRODUCT = {"h2": 3, "x3": 6, "f32": 1, "h1": 1}  # "h1": the labelled fp16 autocast mirror (SCREAM_GEMM=h1), never the headline
 # context only, never `peak`: what a pure stream of v_mfma_f32_32x32x16_{bf16,f16} on random register operands sustains at
 # the 1400 W socket cap (tools/ubench/mfma_energy.py: profiles/r02_ubench_mfma_energy.txt 1.84 PFLOP/s bf16 at 1.80 GHz;
 # profiles/r03_ubench_mfma_energy.txt 1.63 PFLOP/s fp16 at 1.63 GHz on a box whose bf16 row read 1.76)
 MEASURED_MFMA_AT_POWER_CAP_TFLOPS = {"x3": 1840.0, "h2": 1627.0, "h1": 1627.0}
 GEMM_NAMES = {0: "gemm<EPI_NONE>", 1: "gemm<EPI_ELU1> (cross-layer q projection)",
-              5: "gemm<EPI_QKV> (q/k/v projection + fused K^T V reduce)",
+              5: "q/k/v projection + fused K^T V reduce (proj_ring_kernel; gemm<EPI_QKV> with SCREAM_RING_PROJ=0 or off the fp16 splits)",
               7: "tail_kernel (attention apply, merge + LayerNorm1, FFN + LayerNorm2 in one launch; N = 256 + 2 x 1024 columns)",
               2: "gemm<EPI_RELU> (FFN 256->1024)", 3: "gemm<EPI_BIAS_RELU> (coor_mlp)",
               4: "gemm<EPI_RES_LN> (merge, FFN 1024->256 + residual + LayerNorm)",
@@ -327,7 +330,8 @@ def main():
     tgt_len = [n for ln in lane_parts for n in ln.batch.tgt_len]
     rows_total = sum(ln.batch.rows_total for ln in lane_parts)
     pair_ids = torch.arange(rank * B, (rank + 1) * B, device=dev, dtype=torch.float32)
-    gathered = [torch.empty(B, sdist.ROW_WIDTH, device=coll_dev) for _ in range(world)] if world > 1 else None
+    # one set of receive buffers PER STREAM in flight: two steps on alternating streams must not all-gather into the same tensors
+    gathered = [[torch.empty(B, sdist.ROW_WIDTH, device=coll_dev) for _ in range(world)] for _ in range(max(1, args.alternate))] if world > 1 else None
 
     dis_thresh = 1.5 if args.workload == "kitti" else 0.1  # evaluate_kitti.py:109 / evaluate_3d_match.py:178
 
@@ -341,19 +345,19 @@ def main():
 
     def step(trace=None, registered=False):
         if alt_streams:  # the whole step on the next stream; nothing joins until fence()
-            st = alt_streams[step_no[0] % len(alt_streams)]
+            k = step_no[0] % len(alt_streams)
             step_no[0] += 1
-            with torch.cuda.stream(st):
-                return step_on_current(trace, registered)
+            with torch.cuda.stream(alt_streams[k]):
+                return step_on_current(trace, registered, k)
         return step_on_current(trace, registered)
 
-    def step_on_current(trace=None, registered=False):
+    def step_on_current(trace=None, registered=False, slot=0):
         outs = lanes.run(dev, lane_parts, lambda ln: lane_step(ln, trace, registered))
         re, te, n_corr = (torch.cat([o[i] for o in outs]) for i in range(3))
         if world > 1:  # the path's only exchange: per-pair metric rows
             rows = torch.zeros(B, sdist.ROW_WIDTH, device=dev)
             rows[:, 0], rows[:, 4], rows[:, 5] = pair_ids, re, te
-            tdist.all_gather(gathered, rows.to(coll_dev))
+            tdist.all_gather(gathered[slot], rows.to(coll_dev))
         return re, te, n_corr
 
     def fence():
@@ -451,6 +455,43 @@ def main():
                "mean_correspondences": round(float(k_v.float().mean().item()), 1),
                "success_RE5_TE_0.3_fraction": round(float(((re_v < 5) & (te_v < 0.3)).float().mean().item()), 3)}
 
+    # ---- the kernels north_star names a roofline for, outside the timed region: HIP events on the launch stream
+    # around back-to-back calls of the 1-NN stage and of the gather + Kabsch solve on lane 0's batch (the whole step's unless
+    # --lanes > 1), with the realistic correspondences of the registered-prediction variant
+    def ev_ms(f, n=20):
+        for _ in range(3):
+            f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            f()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    ln0 = lane_parts[0]
+    b0 = ln0.batch
+    tgt_xyz0, tgt_row0_0 = b0.xyz[b0.rows_src:], (b0.tgt_row0 - b0.rows_src).contiguous()
+    nn_call = lambda: ops.nn_search(ln0.reg_pred, tgt_xyz0, b0.src_row0, b0.src_len_dev, tgt_row0_0, b0.tgt_len_dev, ln0.s,
+                                    max(b0.src_len), max(b0.tgt_len), dis_thresh)
+    idx0, _, valid0 = nn_call()
+    kab_call = lambda: ops.kabsch_corr(b0.xyz[: b0.rows_src], tgt_xyz0, b0.src_row0, b0.src_len_dev, tgt_row0_0, idx0, valid0, ln0.s, ln0.c)
+    nn_ms, kab_ms = ev_ms(nn_call), ev_ms(kab_call)
+    # the embedding and the K^T V finalize of the stem (every row of the batch) the same way: inside the timed region their
+    # launches overlap the other step in flight, so the in-forward event times are not the kernels' own
+    from scream_amd.model import pe_dim_t
+    w_ = lambda k: sd[k].to(dev).contiguous()
+    emb_args = (b0.xyz, b0.tile_cloud, b0.center, pe_dim_t().to(dev), w_("embedding.weight")[:, :, 0].contiguous(), w_("embedding.bias"),
+                w_("pre_norm.weight"), w_("pre_norm.bias"))
+    emb_ms = ev_ms(lambda: ops.pe_embed_ln(*emb_args, frag=True))
+    kv_part = torch.zeros(b0.rows_total // 128, 8, 1056, device=dev)
+    kv_img = torch.zeros(2 * b0.n_pairs, lib.scream_kv_image_bytes(), device=dev, dtype=torch.uint8)
+    kvf_ms = ev_ms(lambda: ops.kv_finalize_x3(kv_part, b0.cloud_row0, b0.cloud_len, 0, 0, 2 * b0.n_pairs, 2 * b0.n_pairs, out=kv_img))
+    k_corr = float(kab_call()[1].sum().item())
+    nn_flop = 8.0 * sum(n * m for n, m in zip(b0.src_len, b0.tgt_len))                       # N M (3 fma + add + compare), SURVEY.md 8d
+    nn_bytes = float(sum(12 * n + 12 * m + 9 * n for n, m in zip(b0.src_len, b0.tgt_len)))   # src_pred, tgt in; idx, dmin, valid out
+    kab_bytes = float(17 * sum(b0.src_len) + 12 * k_corr + 64 * b0.n_pairs)                  # src + idx + valid per point, one target row per correspondence, T out
+
     # ---- per-kernel times recorded inside the timed region ------------------------------------
     ms = (C.c_float * cap)()
     kind = (C.c_int32 * cap)()
@@ -497,6 +538,28 @@ def main():
                       "tflops_padded": round(2.0 * k_[1] * k_[2] * k_[3] / (v["ms"] / v["launches"] * 1e-3) / 1e12, 1)}
                      for k_, v in sorted(by_shape.items())]
 
+    # roofline.secondary: the HBM- / VALU-bound kernels of the step against THEIR roofs (algorithmic bytes or flops per call over
+    # the HIP-event time of the call; peaks from MI355X_MICROARCH.md: HBM 8 TB/s, 78.6 TFLOP/s of unpacked fp32 fma on 256 CUs)
+    def hbm_row(name, ms_call, nbytes, note):
+        return {"kernel": name, "bound": "hbm", "avg_ms": round(ms_call, 4), "algorithmic_bytes_per_call": round(nbytes),
+                "achieved": round(nbytes / (ms_call * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                "frac": round(nbytes / (ms_call * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "note": note}
+    secondary = [{"kernel": "scream_nn_search (A7: target prep + key init, nn_search_kernel, finalize)", "bound": "valu", "avg_ms": round(nn_ms, 4),
+                  "algorithmic_flop_per_call": nn_flop, "achieved": round(nn_flop / (nn_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_VALU_TFLOPS,
+                  "unit": "TFLOP/s", "frac": round(nn_flop / (nn_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS, 4),
+                  "algorithmic_bytes_per_call": round(nn_bytes), "algorithmic_GBps": round(nn_bytes / (nn_ms * 1e-3) / 1e9, 2),
+                  "note": "brute force over LDS-staged targets: N M x 8 flop over 12 (N + M) + 9 N bytes -- VALU-bound by three orders of "
+                          "magnitude, not HBM-bound (SURVEY.md 8d); HIP events around back-to-back calls on the launch stream"}]
+    secondary.append(hbm_row("pe_embed_ln_kernel (A1)", emb_ms, b0.rows_total * (12 + 1024.0),
+                             "12 B of coordinates in, 1 KB of features out per row; HIP events around back-to-back calls"))
+    secondary.append(hbm_row("kv_finalize_x3_kernel (A3 reduce, second stage; the stem's launch: every cloud of the batch)", kvf_ms,
+                             kv_part.numel() * 4.0 + kv_img.numel(),
+                             "the K^T V partials of every 128-row tile in (33 KB per tile), one operand image per cloud out: 90 MB per "
+                             "launch behind a reduction whose depth is a cloud's ~40 tiles -- latency, not bandwidth"))
+    secondary.append(hbm_row("kabsch_corr_kernel (A8 + A9)", kab_ms, kab_bytes,
+                             "17 B per source point + 12 B per correspondence (%.0f per pair with the registered prediction): one workgroup "
+                             "per pair, latency-bound" % (k_corr / b0.n_pairs)))
+
     gb = net.gemm_backend
     split_backend = gb in ("h2", "x3", "h1")
     n_prod = MFMAS_PER_PRODUCT[gb]
@@ -530,7 +593,7 @@ def main():
                    "counters": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE, separate passes, %d lane(s)" % trec.get("lanes", 1),
                    "source": tpath}
     peak = PEAK_16BIT_DENSE_TFLOPS / n_prod if split_backend else PEAK_FP32_MATRIX_TFLOPS
-    kernel_desc = (("tail_kernel<%s> + gemm_split_kernel<%s> (fp32 operands split into %s, %d x v_mfma_f32_32x32x16_%s per "
+    kernel_desc = (("tail_kernel<%s> + proj_ring_kernel / gemm_split_kernel<%s> (fp32 operands split into %s, %d x v_mfma_f32_32x32x16_%s per "
                     "product, fp32 accumulate; peak = 16-bit dense 2500 TFLOP/s / %d; achieved = fp32-equivalent algorithmic GEMM "
                     "flops of SURVEY.md 8d over the time a GEMM-class launch was running; the attention-apply products and the "
                     "fused K^T V epilogue's own MFMAs are not counted)")
@@ -559,7 +622,7 @@ def main():
                        "gemm_backend": net.gemm_backend},
             "roofline": {"bound": "mfma", "kernel": kernel_desc,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "secondary": secondary,
                          "mfma_tflops_issued": round(achieved * n_prod, 1),
                          "frac_of_fp32_matrix_peak": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
                          **({"frac_of_measured_mfma_rate_at_power_cap": round(achieved * n_prod / MEASURED_MFMA_AT_POWER_CAP_TFLOPS[gb], 4)} if split_backend else {}),

@@ -9,12 +9,41 @@ namespace {
 constexpr int D = SCREAM_D_MODEL;
 constexpr int NPF = 84;  // num_pos_feats = 256 // 3 // 2 * 2 (models/transformer.py:148)
 
+// sin and cos of one argument for the position embedding: three-term Cody-Waite reduction by pi / 2 (the first two constants are
+// short enough for q times them to be exact for |q| < 2^13) and the Cephes single-precision kernels on [-pi/4, pi/4]: absolute
+// error <= 1e-7 for |p| <= 8192 and <= 1.1 ulp for |p| <= 100 (normalised coordinates give |p| <= 2 pi; checked on the host
+// against float64 over 6 x 10^6 arguments and on the device by test_pe_sine_embedding_against_float64) in ~26 vector
+// instructions, where sincosf spends three times that on a reduction that must also cover |p| ~ 1e38.  Larger arguments,
+// inf and NaN take sincosf.
+__device__ __forceinline__ void sincos_pe(float p, float* sn, float* cs) {
+    if (!(fabsf(p) <= 8192.0f)) {  // (also NaN / inf)
+        sincosf(p, sn, cs);
+        return;
+    }
+    const float q = rintf(p * 0.636619772367581343f);                       // nearest multiple of pi / 2
+    float r = __builtin_fmaf(q, -1.5703125f, p);                             // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188e-8 + ...
+    r = __builtin_fmaf(q, -4.837512969970703125e-4f, r);
+    r = __builtin_fmaf(q, -7.54978995489188e-8f, r);
+    const float z = r * r;
+    const float ps = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float pc = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                                    __builtin_fmaf(-0.5f, z, 1.0f));
+    const int n = (int)q;
+    const float s0 = (n & 1) ? pc : ps, c0 = (n & 1) ? ps : pc;
+    *sn = (n & 2) ? -s0 : s0;
+    *cs = ((n + 1) & 2) ? -c0 : c0;
+}
+
 // feats[row] = LN(pe(xyz[row]) + W_e (xyz[row] - center[cloud]) + b_e); models/pointnet.py:45-48.
 // Feature f < 252: axis a = f / 84, i = f % 84, value sin(p) for even i, cos(p) for odd i with
 // p = (x_a * 2 pi) / dim_t[i] (models/transformer.py:172-176); features 252..255 are the zero pad (:179).
-// One block = one 32-row group, eight rows per wave.  FRAG: the group goes out FRAGMENT-major (SCREAM_ACT_FRAG,
-// include/scream_hip.h) through an LDS tile -- the layout the split GEMM and the layer tail read, which used to cost a separate
-// scream_act_layout pass over the features (118 us per step); the values are the row-major kernel's, bit for bit.
+// One block = one 32-row group, eight rows per wave.  Lane l owns the FOUR consecutive features 4 l .. 4 l + 3 (round 4): dim_t[2 j] ==
+// dim_t[2 j + 1] (transformer.py:168-170), so the features 2 j, 2 j + 1 are the sine and the cosine of the SAME argument -- two
+// sincosf per lane and row where a lane that owned features 64 apart evaluated four sinf AND four cosf (a per-lane choice between
+// two calls runs both) behind four divisions: the kernel was bound by its ~440 vector instructions per row, 0.26 of the HBM rate
+// for 1 KB written per row; 84 = 4 x 21 puts the axis boundaries on lane boundaries (lanes 0-20 | 21-41 | 42-62 | lane 63 = the pad).
+// FRAG: the group goes out FRAGMENT-major (SCREAM_ACT_FRAG, include/scream_hip.h) through an LDS tile -- the layout the projection
+// and the layer tail read; the values are the row-major kernel's, bit for bit.
 template <bool FRAG>
 __global__ __launch_bounds__(256) void pe_embed_ln_kernel(const float* __restrict__ xyz,
                                                          const int32_t* __restrict__ tile_cloud,
@@ -32,39 +61,34 @@ __global__ __launch_bounds__(256) void pe_embed_ln_kernel(const float* __restric
     const int cloud = tile_cloud[row0 / SCREAM_ROW_TILE];
     const float c[3] = {center[cloud * 3 + 0], center[cloud * 3 + 1], center[cloud * 3 + 2]};
     const float two_pi = 6.283185307179586f;  // fp32(1.0 * 2 * math.pi), transformer.py:155,171
-    float ew[4][3], eb[4], g[4], be[4], dt[4];
-    int ax[4];
-    bool odd[4];
+    const int f0 = 4 * lane;
+    const int ax = lane < 63 ? lane / 21 : -1;       // axis of the lane's four features (-1: the zero pad)
+    const int i0 = ax >= 0 ? f0 - ax * NPF : 0;      // even: (i0, i0 + 1) and (i0 + 2, i0 + 3) are (sin, cos) pairs
+    const float dt0 = dim_t[i0], dt1 = dim_t[i0 + 2];
+    float ew[4][3];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int f = lane + 64 * k;
-        ew[k][0] = emb_w[f * 3 + 0];
-        ew[k][1] = emb_w[f * 3 + 1];
-        ew[k][2] = emb_w[f * 3 + 2];
-        eb[k] = emb_b[f];
-        g[k] = gamma[f];
-        be[k] = beta[f];
-        ax[k] = f < 3 * NPF ? f / NPF : -1;
-        const int i = f < 3 * NPF ? f - ax[k] * NPF : 0;
-        dt[k] = dim_t[i];
-        odd[k] = i & 1;
-    }
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ew[k][a] = emb_w[(f0 + k) * 3 + a];
+    const f32x4 eb = *reinterpret_cast<const f32x4*>(emb_b + f0), g = *reinterpret_cast<const f32x4*>(gamma + f0),
+                be = *reinterpret_cast<const f32x4*>(beta + f0);
     for (int rr = 0; rr < 8; ++rr) {
         const int rl = wave * 8 + rr;
         const int64_t row = row0 + rl;
         const float x[3] = {xyz[row * 3 + 0], xyz[row * 3 + 1], xyz[row * 3 + 2]};
         const float xe[3] = {x[0] - c[0], x[1] - c[1], x[2] - c[2]};
+        float pe[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ax >= 0) {
+            const float xa = (ax == 0 ? x[0] : ax == 1 ? x[1] : x[2]) * two_pi;
+            sincos_pe(xa / dt0, &pe[0], &pe[1]);
+            sincos_pe(xa / dt1, &pe[2], &pe[3]);
+        }
         float v[4];
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float pe = 0.f;
-            if (ax[k] >= 0) {
-                const float p = ((ax[k] == 0 ? x[0] : ax[k] == 1 ? x[1] : x[2]) * two_pi) / dt[k];
-                pe = odd[k] ? cosf(p) : sinf(p);
-            }
             const float e = ew[k][0] * xe[0] + ew[k][1] * xe[1] + ew[k][2] * xe[2] + eb[k];
-            v[k] = pe + e;
+            v[k] = pe[k] + e;
             s += v[k];
         }
         const float mean = wave_sum(s) * (1.0f / D);
@@ -75,13 +99,11 @@ __global__ __launch_bounds__(256) void pe_embed_ln_kernel(const float* __restric
             q += d * d;
         }
         const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+        f32x4 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int f = lane + 64 * k;
-            const float o = (v[k] - mean) * rstd * g[k] + be[k];
-            if (FRAG) tile[rl * LDT + f] = o;
-            else feats[row * D + f] = o;
-        }
+        for (int k = 0; k < 4; ++k) o[k] = (v[k] - mean) * rstd * g[k] + be[k];
+        if (FRAG) *reinterpret_cast<f32x4*>(&tile[rl * LDT + f0]) = o;
+        else *reinterpret_cast<f32x4*>(feats + row * D + f0) = o;  // 1 KiB per wave instruction
     }
     if (FRAG) {
         __syncthreads();

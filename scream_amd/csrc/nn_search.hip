@@ -45,9 +45,36 @@ __global__ __launch_bounds__(256) void nn_prep_kernel(const float* __restrict__ 
     *reinterpret_cast<f32x4*>(ref_prep + row * 4) = o;
 }
 
-__global__ __launch_bounds__(256) void nn_init_keys_kernel(uint64_t* __restrict__ keys, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) keys[i] = ~0ull;
+// everything the search needs set up, as ONE launch (round 4; three before: the stage is launch-bound at 5 k points): blocks
+// [0, q_blocks) initialise the keys and the outputs of every packed query row (rows outside any cloud keep idx -1, dmin inf,
+// valid 0), the other p_blocks x n_pairs blocks prepare the targets like nn_prep_kernel
+__global__ __launch_bounds__(256) void nn_setup_kernel(uint64_t* __restrict__ keys, int32_t* __restrict__ idx, float* __restrict__ dmin,
+                                                      uint8_t* __restrict__ valid, int64_t n_q, unsigned q_blocks, unsigned p_blocks,
+                                                      const float* __restrict__ ref, const int32_t* __restrict__ r_row0,
+                                                      const int32_t* __restrict__ r_len, const float* __restrict__ s,
+                                                      float* __restrict__ ref_prep) {
+    if (blockIdx.x < q_blocks) {
+        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (i < n_q) {
+            keys[i] = ~0ull;
+            idx[i] = -1;
+            dmin[i] = __builtin_inff();
+            valid[i] = 0;
+        }
+        return;
+    }
+    const unsigned b = blockIdx.x - q_blocks;
+    const int p = b / p_blocks;
+    const int i = (b % p_blocks) * 256 + threadIdx.x;
+    if (i >= r_len[p]) return;
+    const int64_t row = (int64_t)r_row0[p] + i;
+    const float sp = s[p];
+    const float bx = __fdiv_rn(ref[row * 3 + 0], sp);
+    const float by = __fdiv_rn(ref[row * 3 + 1], sp);
+    const float bz = __fdiv_rn(ref[row * 3 + 2], sp);
+    const float sb = __fadd_rn(__fadd_rn(__fmul_rn(bx, bx), __fmul_rn(by, by)), __fmul_rn(bz, bz));
+    f32x4 o = {bx, by, bz, sb};
+    *reinterpret_cast<f32x4*>(ref_prep + row * 4) = o;
 }
 
 // grid (ceil(max_q_len/QB), r_splits, n_pairs)
@@ -71,6 +98,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float* __restrict_
     const int64_t qrow0 = q_row0[p];
     const float* rp = ref_prep + (int64_t)r_row0[p] * 4;
 
+    const bool wave_has_queries = qb0 + (tid & ~63) < nq;  // wave-uniform: the wave's lowest query index (u = 0, lane 0) exists
     float ax[QPT], ay[QPT], az[QPT], sa[QPT], best[QPT];
     int bi[QPT];
 #pragma unroll
@@ -91,6 +119,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float* __restrict_
         for (int i = tid; i < cnt; i += 256)
             *reinterpret_cast<f32x4*>(tile + i * 4) = *reinterpret_cast<const f32x4*>(rp + (int64_t)(jt + i) * 4);
         __syncthreads();
+        if (!wave_has_queries) continue;  // (the last block of a cloud: 5 135 queries leave waves 1-3 of the sixth block without any)
 #pragma unroll 4
         for (int j = 0; j < cnt; ++j) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(tile + j * 4);  // wave-uniform address: broadcast
@@ -220,14 +249,12 @@ extern "C" int scream_nn_search(const float* query, const float* ref, const int3
     if (n_pairs == 0 || q_rows_total == 0) return 0;
     hipStream_t st = as_stream(stream);
     const unsigned qblk = (unsigned)((q_rows_total + 255) / 256);
-    nn_init_keys_kernel<<<dim3(qblk), dim3(256), 0, st>>>(keys, q_rows_total);
-    SCREAM_LAUNCH_CHECK();
-    nn_fill_padding_kernel<<<dim3(qblk), dim3(256), 0, st>>>(idx, dmin, valid, q_rows_total);
+    const unsigned pblk = max_q_len > 0 ? (unsigned)((max_r_len + 255) / 256) : 0;  // (no queries: nothing reads the prepared targets)
+    SCREAM_REQUIRE((uint64_t)qblk + (uint64_t)pblk * n_pairs < (1ull << 31), SCREAM_EUNSUPPORTED);
+    nn_setup_kernel<<<dim3(qblk + pblk * n_pairs), dim3(256), 0, st>>>(keys, idx, dmin, valid, q_rows_total, qblk, pblk, ref, r_row0, r_len, s, ref_prep);
     SCREAM_LAUNCH_CHECK();
     if (max_q_len == 0) return 0;
     if (max_r_len > 0) {
-        nn_prep_kernel<<<dim3((max_r_len + 255) / 256, n_pairs), dim3(256), 0, st>>>(ref, r_row0, r_len, s, ref_prep);
-        SCREAM_LAUNCH_CHECK();
         const int qblocks = (max_q_len + QB - 1) / QB;
         // split the target range until the grid has >= ~4 blocks per CU; every split is a whole number of LDS tiles
         int splits = (1024 + qblocks * n_pairs - 1) / (qblocks * n_pairs);

@@ -80,6 +80,21 @@ struct SplitH2 {
         p[0][i] = a;
         p[1][i] = (_Float16)__builtin_fmaf(x, s, -(float)a);
     }
+    // elements i (even) and i + 1 at once, the four v_fma_mix instructions spelled out: left to itself hipcc turns half of the
+    // pairs back into multiply + v_cvt_pk_f16_f32 + two converts + two fmas + v_cvt_pk (eight instructions where these are four)
+    static __device__ __forceinline__ void split2s(float x0, float x1, float s, int i, vec (&p)[2]) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        unsigned hi, lo;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(x0), "v"(s));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(x1), "v"(s));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x0), "v"(s), "v"(hi));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(x1), "v"(s), "v"(hi));
+        u32x4 a = __builtin_bit_cast(u32x4, p[0]), b = __builtin_bit_cast(u32x4, p[1]);
+        a[i >> 1] = hi;
+        b[i >> 1] = lo;
+        p[0] = __builtin_bit_cast(vec, a);
+        p[1] = __builtin_bit_cast(vec, b);
+    }
     static __device__ __forceinline__ f32x16 mfma(vec a, vec b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     template <bool MIRROR = false>
     static __device__ __forceinline__ void products(f32x16& acc, const vec (&x)[2], const vec (&y)[2], const f32x16& c0) {
@@ -101,6 +116,10 @@ struct SplitH1 {
     typedef f16x8 vec;
     static __device__ __forceinline__ void split1(float x, int i, vec (&p)[1]) { p[0][i] = (_Float16)x; }
     static __device__ __forceinline__ void split1s(float x, float s, int i, vec (&p)[1]) { p[0][i] = (_Float16)__builtin_fmaf(x, s, 0.0f); }
+    static __device__ __forceinline__ void split2s(float x0, float x1, float s, int i, vec (&p)[1]) {
+        split1s(x0, s, i, p);
+        split1s(x1, s, i + 1, p);
+    }
     static __device__ __forceinline__ f32x16 mfma(vec a, vec b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     template <bool MIRROR = false>
     static __device__ __forceinline__ void products(f32x16& acc, const vec (&x)[1], const vec (&y)[1], const f32x16& c0) {
@@ -113,6 +132,18 @@ template <class SP>
 __device__ __forceinline__ void split8(const f32x4 lo, const f32x4 hi, typename SP::vec (&p)[SP::NP]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) SP::split1(i < 4 ? lo[i] : hi[i - 4], i, p);
+}
+
+// the same for (lo, hi) * s with an exact power of two s (1 for an operand that carries its scale already): the fp16 splits go
+// through split2s (one v_fma_mix per plane and element), the bf16 split ignores s (it is scale free; callers pass 1)
+template <class SP>
+__device__ __forceinline__ void split8s(const f32x4 lo, const f32x4 hi, float s, typename SP::vec (&p)[SP::NP]) {
+    if constexpr (SP::SCALED) {
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) SP::split2s(i < 4 ? lo[i] : hi[i - 4], i < 4 ? lo[i + 1] : hi[i - 3], s, i, p);
+    } else {
+        split8<SP>(lo, hi, p);
+    }
 }
 
 // 2^e as a float, e in [-126, 127]

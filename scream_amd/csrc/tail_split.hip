@@ -55,6 +55,12 @@
 
 #include "ring.h"
 
+#ifndef T_MIX
+// fp16 splits: operand planes by v_fma_mix (split.h: split2s), bit 0 in the FFN's relu / split ride (the default: 103 -> 52 vector
+// instructions per down stage, bit-identical, 1.043 vs 1.046 ms per 333 k-row launch), bit 1 in norm1, the apply and the y planes
+// as well (measured SLOWER, 1.057 ms: the asm statements keep hipcc from packing the norm arithmetic into v_pk_* -- profiles/r04_tail_mix_ab.txt)
+#define T_MIX 1
+#endif
 #ifndef T_DEFER_H2
 #define T_DEFER_H2 2  // SplitH2: MFMA groups of a stage deferred across the barrier into the next stage (1 or 2)
 #endif
@@ -272,8 +278,12 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
     };
     auto apply_split_pair = [&](int k, V (&ap)[2][NP], float S) {  // elements 2k, 2k+1: (aT * Z) * S, then the operand split
         const int s2 = k >> 2, j = (2 * k) & 7;
+        if constexpr (SP::SCALED && (T_MIX & 2)) {
+            SP::split2s((aT[2 * k] * Zs) * S, (aT[2 * k + 1] * Zs) * S, 1.0f, j, ap[s2]);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) SP::split1((aT[2 * k + e] * Zs) * S, j + e, ap[s2]);
+            for (int e = 0; e < 2; ++e) SP::split1((aT[2 * k + e] * Zs) * S, j + e, ap[s2]);
+        }
     };
     // the pieces of one apply as they ride in group g of a 16-group stage: operands consumed in groups 0-3
     auto apply_ride = [&](f32x4 (&qb)[4], int g, V (&ap)[2][NP], float S, int tile_tag) {
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
 #pragma unroll
                         for (int k = 0; k < 4; ++k) v[a2][k] = acc[b][4 * a + k] * rstd * g4[k] + b4[k];
                     }
-                    split8<SP>(v[0], v[1], mp[2 * b + s2]);
+                    if (T_MIX & 2) split8s<SP>(v[0], v[1], 1.0f, mp[2 * b + s2]); else split8<SP>(v[0], v[1], mp[2 * b + s2]);
                 }
         }
 
@@ -470,10 +480,24 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         // relu + split of elements 2k, 2k+1 of the finished h^T tile into the B-operand planes of the down GEMM
         auto split_pair = [&](int k, V (&hout)[2][NP]) {
             const int s2 = k >> 2, j = (2 * k) & 7;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float x = fmaxf(hT[2 * k + e], 0.f);
-                SP::split1(SP::SCALED ? x * sc.ch : x, j + e, hout[s2]);
+            // relu as ONE v_max_f32: fmaxf() (and every builtin that folds to it) costs a second instruction that quiets a NaN the
+            // accumulator cannot hold
+            float x0, x1;
+            if (T_MIX & 1) {
+                asm("v_max_f32 %0, 0, %1" : "=v"(x0) : "v"(hT[2 * k]));
+                asm("v_max_f32 %0, 0, %1" : "=v"(x1) : "v"(hT[2 * k + 1]));
+            } else {
+                x0 = fmaxf(hT[2 * k], 0.f);
+                x1 = fmaxf(hT[2 * k + 1], 0.f);
+            }
+            if constexpr (SP::SCALED && (T_MIX & 1)) {
+                SP::split2s(x0, x1, sc.ch, j, hout[s2]);  // the planes of x 2^e, one v_fma_mix each (split.h)
+            } else if constexpr (SP::SCALED) {
+                SP::split1(x0 * sc.ch, j, hout[s2]);
+                SP::split1(x1 * sc.ch, j + 1, hout[s2]);
+            } else {
+                SP::split1(x0, j, hout[s2]);
+                SP::split1(x1, j + 1, hout[s2]);
             }
         };
         // XLOAD: x segment to request in this stage (-1: none)
@@ -658,7 +682,10 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
                         if (!(T_ABLATE & (16 | 128)) || o[0] + o[1] + o[2] + o[3] == 123.456f) *reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256) = o;
                         o2[a2] = o;
                     }
-                    if (NQ) split8<SP>(o2[0] * sc.s_y, o2[1] * sc.s_y, yp[NQ ? 2 * b + s2 : 0]);  // B operand of the query stages below
+                    if (NQ) {  // B operand of the query stages below
+                        if (T_MIX & 2) split8s<SP>(o2[0], o2[1], sc.s_y, yp[NQ ? 2 * b + s2 : 0]);
+                        else split8<SP>(o2[0] * sc.s_y, o2[1] * sc.s_y, yp[NQ ? 2 * b + s2 : 0]);
+                    }
                 }
         }
         if constexpr (NQ) {

@@ -206,6 +206,31 @@ def test_elu_feature_map_is_within_two_ulp_of_float64():
 
 
 # ------------------------------------------------------------------------------ A1 embedding
+def test_pe_sine_embedding_against_float64():
+    """The sine embedding (models/transformer.py:157-179) by itself -- zero 1x1-conv weights, unit pre_norm, so the kernel's output is
+    LayerNorm(PE(xyz)) -- against float64, on normalised coordinates (|p| <= 2 pi), on coordinates of hundreds of units (the kernel's
+    own argument reduction, csrc/embed.hip:sincos_pe) and beyond its range (the libm path)."""
+    from scream_amd.model import pe_dim_t
+    from scream_amd.packing import PackedBatch
+    g = torch.Generator().manual_seed(5)
+    # (the fp32 LayerNorm behind the embedding -- outputs up to ~2.5, ulp 2.4e-7, a few roundings -- accounts for ~5e-7 by itself)
+    for scale, tol in ((1.0, 1.2e-6), (300.0, 1.2e-6), (5000.0, 1.2e-6)):
+        src = (torch.rand(300, 3, generator=g) * 2 - 1) * scale
+        tgt = (torch.rand(140, 3, generator=g) * 2 - 1) * scale
+        b = PackedBatch.from_pairs([dev(src)], [dev(tgt)], [dev(torch.zeros(3))])
+        z = lambda *sh: dev(torch.zeros(*sh))
+        feats = ops.pe_embed_ln(b.xyz, b.tile_cloud, b.center, dev(pe_dim_t()), z(256, 3), z(256), dev(torch.ones(256)), z(256)).cpu().double()
+        dim_t = pe_dim_t()  # fp32, as the reference holds it
+        for x32, r0 in ((src, 0), (tgt, b.rows_src)):
+            p = (x32 * np.float32(2 * np.pi))[:, :, None] / dim_t[None, None, :]          # the reference's fp32 argument ...
+            p = p.double()                                                                # ... evaluated exactly from there on
+            pe = torch.stack([p[:, :, 0::2].sin(), p[:, :, 1::2].cos()], dim=3).flatten(2).flatten(1)
+            pe = torch.cat([pe, torch.zeros(pe.shape[0], 4, dtype=torch.float64)], dim=1)
+            want = (pe - pe.mean(1, keepdim=True)) / (pe.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt()
+            err = float((feats[r0:r0 + x32.shape[0]] - want).abs().max())
+            assert err <= tol, (scale, err)
+
+
 def test_pe_embed_prenorm_vs_oracle(golden):
     from scream_amd.model import pe_dim_t
     from scream_amd.packing import PackedBatch

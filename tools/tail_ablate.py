@@ -106,8 +106,12 @@ def run():
                                                                 timg.data_ptr(), gam.data_ptr(), bet.data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(), None, M,
                                                                 split, ctypes.byref(EX), st))))
     print("%-50s %9s %9s %9s %10s %9s  (M=%d, split %s; merge + FFN = %.1f GFLOP)" % ("variant", "ms", "sclk MHz", "power W", "J/launch", "TFLOP/s", M, os.environ.get("T_SPLIT", "h2"), 2.0 * M * 256 * 2304 / 1e9))
+    y_ref = None
     for label, call in calls:
         call(); torch.cuda.synchronize(); time.sleep(0.4)
+        if "fused tail: full" in label:  # every build of the whole kernel must give the same bits (T_TAGS: A/B of code variants)
+            if y_ref is None: y_ref = y.clone()
+            else: print("# %s: max |y - y of the first full build| = %g" % (label, float((y - y_ref).abs().max())), flush=True)
         t0 = time.time(); n = 0
         while time.time() - t0 < secs:
             for _ in range(10): call()
