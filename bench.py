@@ -233,6 +233,9 @@ def main():
                          "rounds 1-2's default was 2); --lanes 1 = one step at a time on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sustain", dest="sustain", action="store_false", help="skip the >= 3 s sustained-rate leg")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false",
+                    help="skip the isolated calls behind roofline.secondary (counter passes: tools/pmc_traffic.py counts steps by the "
+                         "dispatches of the embedding kernel)")
     ap.add_argument("--no-power", action="store_true",
                     help="do not sample rocm-smi beside the variant steps (under rocprofv3 its preload has initialised the GPU in "
                          "this process, and starting another program from it is refused on the GPU boxes)")
@@ -469,28 +472,30 @@ def main():
         e1.synchronize()
         return e0.elapsed_time(e1) / n
 
-    ln0 = lane_parts[0]
-    b0 = ln0.batch
-    tgt_xyz0, tgt_row0_0 = b0.xyz[b0.rows_src:], (b0.tgt_row0 - b0.rows_src).contiguous()
-    nn_call = lambda: ops.nn_search(ln0.reg_pred, tgt_xyz0, b0.src_row0, b0.src_len_dev, tgt_row0_0, b0.tgt_len_dev, ln0.s,
-                                    max(b0.src_len), max(b0.tgt_len), dis_thresh)
-    idx0, _, valid0 = nn_call()
-    kab_call = lambda: ops.kabsch_corr(b0.xyz[: b0.rows_src], tgt_xyz0, b0.src_row0, b0.src_len_dev, tgt_row0_0, idx0, valid0, ln0.s, ln0.c)
-    nn_ms, kab_ms = ev_ms(nn_call), ev_ms(kab_call)
-    # the embedding and the K^T V finalize of the stem (every row of the batch) the same way: inside the timed region their
-    # launches overlap the other step in flight, so the in-forward event times are not the kernels' own
-    from scream_amd.model import pe_dim_t
-    w_ = lambda k: sd[k].to(dev).contiguous()
-    emb_args = (b0.xyz, b0.tile_cloud, b0.center, pe_dim_t().to(dev), w_("embedding.weight")[:, :, 0].contiguous(), w_("embedding.bias"),
-                w_("pre_norm.weight"), w_("pre_norm.bias"))
-    emb_ms = ev_ms(lambda: ops.pe_embed_ln(*emb_args, frag=True))
-    kv_part = torch.zeros(b0.rows_total // 128, 8, 1056, device=dev)
-    kv_img = torch.zeros(2 * b0.n_pairs, lib.scream_kv_image_bytes(), device=dev, dtype=torch.uint8)
-    kvf_ms = ev_ms(lambda: ops.kv_finalize_x3(kv_part, b0.cloud_row0, b0.cloud_len, 0, 0, 2 * b0.n_pairs, 2 * b0.n_pairs, out=kv_img))
-    k_corr = float(kab_call()[1].sum().item())
-    nn_flop = 8.0 * sum(n * m for n, m in zip(b0.src_len, b0.tgt_len))                       # N M (3 fma + add + compare), SURVEY.md 8d
-    nn_bytes = float(sum(12 * n + 12 * m + 9 * n for n, m in zip(b0.src_len, b0.tgt_len)))   # src_pred, tgt in; idx, dmin, valid out
-    kab_bytes = float(17 * sum(b0.src_len) + 12 * k_corr + 64 * b0.n_pairs)                  # src + idx + valid per point, one target row per correspondence, T out
+    if args.secondary:
+        ln0 = lane_parts[0]
+        b0 = ln0.batch
+        tgt_xyz0, tgt_row0_0 = b0.xyz[b0.rows_src:], (b0.tgt_row0 - b0.rows_src).contiguous()
+        nn_call = lambda: ops.nn_search(ln0.reg_pred, tgt_xyz0, b0.src_row0, b0.src_len_dev, tgt_row0_0, b0.tgt_len_dev, ln0.s,
+                                        max(b0.src_len), max(b0.tgt_len), dis_thresh)
+        idx0, _, valid0 = nn_call()
+        kab_call = lambda: ops.kabsch_corr(b0.xyz[: b0.rows_src], tgt_xyz0, b0.src_row0, b0.src_len_dev, tgt_row0_0, idx0, valid0, ln0.s, ln0.c)
+        nn_ms, kab_ms = ev_ms(nn_call), ev_ms(kab_call)
+        # the embedding and the K^T V finalize of the stem (every row of the batch) the same way: inside the timed region their
+        # launches overlap the other step in flight, so the in-forward event times are not the kernels' own
+        from scream_amd.model import pe_dim_t
+        w_ = lambda k: sd[k].to(dev).contiguous()
+        emb_args = (b0.xyz, b0.tile_cloud, b0.center, pe_dim_t().to(dev), w_("embedding.weight")[:, :, 0].contiguous(), w_("embedding.bias"),
+                    w_("pre_norm.weight"), w_("pre_norm.bias"))
+        emb_ms = ev_ms(lambda: ops.pe_embed_ln(*emb_args, frag=True))
+        kv_part = torch.zeros(b0.rows_total // 128, 8, 1056, device=dev)
+        kv_img = torch.zeros(2 * b0.n_pairs, lib.scream_kv_image_bytes(), device=dev, dtype=torch.uint8)
+        kvf_ms = ev_ms(lambda: ops.kv_finalize_x3(kv_part, b0.cloud_row0, b0.cloud_len, 0, 0, 2 * b0.n_pairs, 2 * b0.n_pairs, out=kv_img))
+        k_corr = float(kab_call()[1].sum().item())
+        nn_flop = 8.0 * sum(n * m for n, m in zip(b0.src_len, b0.tgt_len))                       # N M (3 fma + add + compare), SURVEY.md 8d
+        nn_bytes = float(sum(12 * n + 12 * m + 9 * n for n, m in zip(b0.src_len, b0.tgt_len)))   # src_pred, tgt in; idx, dmin, valid out
+        kab_bytes = float(17 * sum(b0.src_len) + 12 * k_corr + 64 * b0.n_pairs)                  # src + idx + valid per point, one target row per correspondence, T out
+
 
     # ---- per-kernel times recorded inside the timed region ------------------------------------
     ms = (C.c_float * cap)()
@@ -538,27 +543,30 @@ def main():
                       "tflops_padded": round(2.0 * k_[1] * k_[2] * k_[3] / (v["ms"] / v["launches"] * 1e-3) / 1e12, 1)}
                      for k_, v in sorted(by_shape.items())]
 
-    # roofline.secondary: the HBM- / VALU-bound kernels of the step against THEIR roofs (algorithmic bytes or flops per call over
-    # the HIP-event time of the call; peaks from MI355X_MICROARCH.md: HBM 8 TB/s, 78.6 TFLOP/s of unpacked fp32 fma on 256 CUs)
-    def hbm_row(name, ms_call, nbytes, note):
-        return {"kernel": name, "bound": "hbm", "avg_ms": round(ms_call, 4), "algorithmic_bytes_per_call": round(nbytes),
-                "achieved": round(nbytes / (ms_call * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                "frac": round(nbytes / (ms_call * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "note": note}
-    secondary = [{"kernel": "scream_nn_search (A7: target prep + key init, nn_search_kernel, finalize)", "bound": "valu", "avg_ms": round(nn_ms, 4),
-                  "algorithmic_flop_per_call": nn_flop, "achieved": round(nn_flop / (nn_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_VALU_TFLOPS,
-                  "unit": "TFLOP/s", "frac": round(nn_flop / (nn_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS, 4),
-                  "algorithmic_bytes_per_call": round(nn_bytes), "algorithmic_GBps": round(nn_bytes / (nn_ms * 1e-3) / 1e9, 2),
-                  "note": "brute force over LDS-staged targets: N M x 8 flop over 12 (N + M) + 9 N bytes -- VALU-bound by three orders of "
-                          "magnitude, not HBM-bound (SURVEY.md 8d); HIP events around back-to-back calls on the launch stream"}]
-    secondary.append(hbm_row("pe_embed_ln_kernel (A1)", emb_ms, b0.rows_total * (12 + 1024.0),
-                             "12 B of coordinates in, 1 KB of features out per row; HIP events around back-to-back calls"))
-    secondary.append(hbm_row("kv_finalize_x3_kernel (A3 reduce, second stage; the stem's launch: every cloud of the batch)", kvf_ms,
-                             kv_part.numel() * 4.0 + kv_img.numel(),
-                             "the K^T V partials of every 128-row tile in (33 KB per tile), one operand image per cloud out: 90 MB per "
-                             "launch behind a reduction whose depth is a cloud's ~40 tiles -- latency, not bandwidth"))
-    secondary.append(hbm_row("kabsch_corr_kernel (A8 + A9)", kab_ms, kab_bytes,
-                             "17 B per source point + 12 B per correspondence (%.0f per pair with the registered prediction): one workgroup "
-                             "per pair, latency-bound" % (k_corr / b0.n_pairs)))
+    secondary = None
+    if args.secondary:
+        # roofline.secondary: the HBM- / VALU-bound kernels of the step against THEIR roofs (algorithmic bytes or flops per call over
+        # the HIP-event time of the call; peaks from MI355X_MICROARCH.md: HBM 8 TB/s, 78.6 TFLOP/s of unpacked fp32 fma on 256 CUs)
+        def hbm_row(name, ms_call, nbytes, note):
+            return {"kernel": name, "bound": "hbm", "avg_ms": round(ms_call, 4), "algorithmic_bytes_per_call": round(nbytes),
+                    "achieved": round(nbytes / (ms_call * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": round(nbytes / (ms_call * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "note": note}
+        secondary = [{"kernel": "scream_nn_search (A7: target prep + key init, nn_search_kernel, finalize)", "bound": "valu", "avg_ms": round(nn_ms, 4),
+                      "algorithmic_flop_per_call": nn_flop, "achieved": round(nn_flop / (nn_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_VALU_TFLOPS,
+                      "unit": "TFLOP/s", "frac": round(nn_flop / (nn_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS, 4),
+                      "algorithmic_bytes_per_call": round(nn_bytes), "algorithmic_GBps": round(nn_bytes / (nn_ms * 1e-3) / 1e9, 2),
+                      "note": "brute force over LDS-staged targets: N M x 8 flop over 12 (N + M) + 9 N bytes -- VALU-bound by three orders of "
+                              "magnitude, not HBM-bound (SURVEY.md 8d); HIP events around back-to-back calls on the launch stream"}]
+        secondary.append(hbm_row("pe_embed_ln_kernel (A1)", emb_ms, b0.rows_total * (12 + 1024.0),
+                                 "12 B of coordinates in, 1 KB of features out per row; HIP events around back-to-back calls"))
+        secondary.append(hbm_row("kv_finalize_x3_kernel (A3 reduce, second stage; the stem's launch: every cloud of the batch)", kvf_ms,
+                                 kv_part.numel() * 4.0 + kv_img.numel(),
+                                 "the K^T V partials of every 128-row tile in (33 KB per tile), one operand image per cloud out: 90 MB per "
+                                 "launch behind a reduction whose depth is a cloud's ~40 tiles -- latency, not bandwidth"))
+        secondary.append(hbm_row("kabsch_corr_kernel (A8 + A9)", kab_ms, kab_bytes,
+                                 "17 B per source point + 12 B per correspondence (%.0f per pair with the registered prediction): one workgroup "
+                                 "per pair, latency-bound" % (k_corr / b0.n_pairs)))
+
 
     gb = net.gemm_backend
     split_backend = gb in ("h2", "x3", "h1")

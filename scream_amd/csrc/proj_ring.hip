@@ -19,6 +19,9 @@
 //         [head][33][32] that scream_kv_finalize_x3 sums per cloud.  K' and V never exist in memory.
 //     In the 8-wave GEMM a query tile's epilogue (a third of its time) ran with the matrix pipe idle -- its block-wide k-loop
 //     barriers keep both waves of a SIMD in lockstep.
+//     (Built first with LDS-DMA "touches" -- one dword per 128-byte line of the NEXT tile's rows, one instruction per stage -- to have
+//     the rows in the L2 before the tile boundary reads them: 3-5 % SLOWER and 3.7 x the HBM fetch traffic by the counters, the
+//     narrow loads are fetched line by line and do not stay; removed -- profiles/r04_ring_proj_prefetch_experiment.txt.)
 //   * work is cut into UNITS of two stages (two query chunks, or the K and V chunk of one head) and every block takes a
 //     CONTIGUOUS range of the launch's units, tile-major: no partial last round (1 302 row tiles on 256 CUs were 5.09 -> 6 rounds
 //     of the old persistent grid), at the price of one extra x tile load per block.  A row's results do not depend on how its
@@ -40,14 +43,13 @@
 #define P_LB 2  // x segments per load batch at a tile boundary (two batches in flight)
 #endif
 #ifndef P_ABLATE
-#define P_ABLATE 0  // tuning aid (tools/proj_ablate.py): 1 no rides (epilogues dropped), 2 no MFMA, 4 no LDS fragment reads, 8 no W DMA after the first two stages, 16 no x prefetch
+#define P_ABLATE 0  // tuning aid (SCREAM_HIPCC_EXTRA builds): 1 no rides (epilogues dropped), 2 no MFMA, 8 no W DMA after the first two stages (-DT_ABLATE=4: no LDS fragment reads)
 #endif
 
 namespace {
 
 constexpr int P_KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;  // 1056
 constexpr int P_SLAB_BYTES = 4 * P_KV_ELEMS * 4;                      // one K^T V tile + Ksum per wave
-constexpr int P_PF_BYTES = 4 * 256;                                   // landing zone of the x prefetch touches (never read)
 constexpr int P_MAX_GRID = 256;
 
 struct ProjArgs {
@@ -73,11 +75,10 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
     constexpr int NP = SP::NP;
     constexpr int STAGE = stage_bytes<SP>();
     constexpr int PIECES = wave_pieces<SP>();   // LDS-DMA weight pieces per wave and stage
-    constexpr int INFLIGHT = PIECES + 1;        // + the x prefetch touch: what a ring wait leaves in flight
+    constexpr int INFLIGHT = PIECES;            // what a ring wait leaves in flight: the pieces issued during the previous stage
     constexpr int NV = 6;                       // ride slots behind every MFMA
-    __shared__ __attribute__((aligned(16))) char smem[T_SLOTS * STAGE + P_SLAB_BYTES + P_PF_BYTES];  // the ONLY LDS object
+    __shared__ __attribute__((aligned(16))) char smem[T_SLOTS * STAGE + P_SLAB_BYTES];  // the ONLY LDS object
     float* slabs = reinterpret_cast<float*>(smem + T_SLOTS * STAGE);
-    char* pf_zone = smem + T_SLOTS * STAGE + P_SLAB_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, r = lane & 31;
@@ -98,20 +99,10 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
         const char* sbase = pa.Wimg + (size_t)img * STAGE + (wave * PIECES + (u & ~3)) * 1024;
         dma_1k(sbase + v_lane16, smem + slot * STAGE + (wave * PIECES + (u & ~3)) * 1024, u & 3);
     };
-    // one dword per 128-byte line of 8 KiB of the NEXT tile's x rows of this wave: brings them into the L2 long before the tile
-    // boundary reads them (the rows of a tile are first-touch HBM data otherwise: ~2 us in the open per tile)
-    const char* pf_base = reinterpret_cast<const char*>(pa.x);
-    auto prefetch_x = [&](unsigned qq) __attribute__((always_inline)) {
-        const char* p = pf_base + (size_t)(qq & 7) * 8192 + lane * 128;
-        if (P_ABLATE & 16) p = reinterpret_cast<const char*>(pa.x) + lane * 128;
-        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(pf_zone + wave * 256), 4, 0, 0);
-    };
 #pragma unroll
     for (int u = 0; u < PIECES; ++u) dma_piece(0, u);
-    prefetch_x(0);
 #pragma unroll
     for (int u = 0; u < PIECES; ++u) dma_piece(1, u);
-    prefetch_x(1);
 
     // ---- per-tile state ---------------------------------------------------------------------------------------------------
     V xp[2][16][NP];     // operand planes of the wave's two row groups: xp[rg][2 blk + s2] = 16-deep step s2 of feature segment blk
@@ -127,9 +118,6 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
         wave_ok = t128 * 128 < pa.M;
         const int64_t row0 = wave_ok ? t * 256 + wave * 64 : t * 256;  // (idle waves recompute the tile's first rows; nothing of it is stored)
         const float* g = pa.x + row0 * SCREAM_D_MODEL + lane * 4;
-        // next tile's rows of this wave, for the prefetch touches (clamped to this tile at the end of the matrix)
-        const int64_t tn = (t + 1) * 256 + wave * 64 + 64 <= pa.M ? t + 1 : t;
-        pf_base = reinterpret_cast<const char*>(pa.x + (tn * 256 + (wave_ok ? wave * 64 : 0)) * SCREAM_D_MODEL);
         valid0 = 0;
         if (wave_ok && pa.S > pa.n_q) {
             const int64_t arow = pa.row_base + t128 * 128;
@@ -235,19 +223,17 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) wf[(g + P_PF - 1) % P_PF][p] = ld_frag<V>(wb + (p * 16 + g + P_PF - 1) * 1024);
             }
-            if (g >= 9 && g < 14) {  // nine requests in five groups: 2 2 2 2 1 (PIECES weight pieces, then the x prefetch touch)
+            if (g >= 9 && g < 13) {  // the PIECES weight pieces of the stage after next, two per group, behind every store of this stage's ride
 #pragma unroll
-                for (int u = (g - 9) * 2; u < (g - 8) * 2; ++u) {
+                for (int u = (g - 9) * 2; u < (g - 8) * 2; ++u)
                     if (u < PIECES) dma_piece(q + 2, u);
-                    else if (u == PIECES) prefetch_x(q + 2);
-                }
             }
             if (!(P_ABLATE & 1)) ride(g);
             group(kind, a, wf[g % P_PF], g, g == 0);
         }
         ++q;
     };
-    static_assert(wave_pieces<SP>() <= 8, "the request schedule of a stage holds nine requests");
+    static_assert(wave_pieces<SP>() <= 8, "the request schedule of a stage holds eight pieces");
     constexpr std::integral_constant<int, 0> kindQ{};
     constexpr std::integral_constant<int, 1> kindKV{};
 

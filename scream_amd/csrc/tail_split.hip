@@ -61,6 +61,9 @@
 // as well (measured SLOWER, 1.057 ms: the asm statements keep hipcc from packing the norm arithmetic into v_pk_* -- profiles/r04_tail_mix_ab.txt)
 #define T_MIX 1
 #endif
+#ifndef T_RIDE0
+#define T_RIDE0 3  // SplitH2: first MFMA group of a down stage that carries a relu / split pair of the ride (eight groups from there); 0 / 3 / 6: 1.044 / 1.040 / 1.041 ms per 333 k-row launch (profiles/r04_tail_ride0_ab.txt)
+#endif
 #ifndef T_DEFER_H2
 #define T_DEFER_H2 2  // SplitH2: MFMA groups of a stage deferred across the barrier into the next stage (1 or 2)
 #endif
@@ -590,7 +593,9 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
                 if (RIDE == 2) apply_ride(qA, g, apA, S_next, tile_next);
                 // the relu / split of the h^T tile the previous stage finished: eight pairs, in every other group (in the first
                 // eight groups when group 14 is deferred)
-                if (decltype(with_split)::value && (ND == 1 ? (g & 1) == 0 : g < 8)) split_pair(ND == 1 ? g >> 1 : g, hout);
+                // (T_RIDE0: the first group that carries a pair -- the h^T tile was completed by the deferred groups flushed at this stage's
+                // top, and a vector instruction that reads it stalls the whole in-order wave, MFMAs included, until those have drained)
+                if (decltype(with_split)::value && (ND == 1 ? (g & 1) == 0 : (g >= T_RIDE0 && g < T_RIDE0 + 8))) split_pair(ND == 1 ? g >> 1 : g - T_RIDE0, hout);
                 mfma_group<SP>(acc[g >> 1], wf[g % T_PF], hin[g & 1], XADD == 0 && g >= 2 && (g & 1) == 0);
             }
             ++q;

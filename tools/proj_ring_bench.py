@@ -25,7 +25,8 @@ def sampler():
         time.sleep(0.05)
 
 
-threading.Thread(target=sampler, daemon=True).start()
+if os.environ.get("P_NOSMI") != "1":  # (under rocprofv3 starting another program from this process is refused on the GPU boxes)
+    threading.Thread(target=sampler, daemon=True).start()
 g = torch.Generator(device=dev).manual_seed(0)
 shapes = [("stem", 333184, 768, 256), ("crossq", 166912, 768, 256), ("crosskv", 166912, 3072, 0)]
 if os.environ.get("P_SHAPES"):

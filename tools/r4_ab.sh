@@ -2,8 +2,8 @@
 set -o pipefail
 export SCREAM_NO_BUILD=1; cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/$1; mkdir -p $O
 for i in 1 2; do
-  timeout -k 10 400 python bench.py --steps 40 --warmup 6 --no-cpu-baseline > $O/on_$i.json 2> $O/on_$i.err || { tail -5 $O/on_$i.err; exit 1; }
-  env $2 timeout -k 10 400 python bench.py --steps 40 --warmup 6 --no-cpu-baseline > $O/off_$i.json 2> $O/off_$i.err || { tail -5 $O/off_$i.err; exit 1; }
+  timeout -k 10 400 python bench.py --steps 40 --warmup 6 --no-cpu-baseline $3 > $O/on_$i.json 2> $O/on_$i.err || { tail -5 $O/on_$i.err; exit 1; }
+  env $2 timeout -k 10 400 python bench.py --steps 40 --warmup 6 --no-cpu-baseline $3 > $O/off_$i.json 2> $O/off_$i.err || { tail -5 $O/off_$i.err; exit 1; }
 done
 python - <<PY
 import json
