@@ -63,7 +63,7 @@ GEMM_NAMES = {0: "gemm<EPI_NONE>", 1: "gemm<EPI_ELU1> (cross-layer q projection)
               7: "tail_kernel (attention apply, merge + LayerNorm1, FFN + LayerNorm2 in one launch; N = 256 + 2 x 1024 columns)",
               2: "gemm<EPI_RELU> (FFN 256->1024)", 3: "gemm<EPI_BIAS_RELU> (coor_mlp)",
               4: "gemm<EPI_RES_LN> (merge, FFN 1024->256 + residual + LayerNorm)",
-              100: "pe_embed_ln_kernel", 101: "kv_finalize_x3_kernel (kv_finalize_tiles_kernel when the layer tail is unfused)", 102: "attn_apply_kernel",
+              100: "pe_embed_ln_kernel", 101: "kv_finalize_image_kernel (kv_finalize_tiles_kernel when the layer tail is unfused)", 102: "attn_apply_kernel",
               103: "coor_head_kernel"}
 
 
@@ -490,7 +490,7 @@ def main():
         emb_ms = ev_ms(lambda: ops.pe_embed_ln(*emb_args, frag=True))
         kv_part = torch.zeros(b0.rows_total // 128, 8, 1056, device=dev)
         kv_img = torch.zeros(2 * b0.n_pairs, lib.scream_kv_image_bytes(), device=dev, dtype=torch.uint8)
-        kvf_ms = ev_ms(lambda: ops.kv_finalize_x3(kv_part, b0.cloud_row0, b0.cloud_len, 0, 0, 2 * b0.n_pairs, 2 * b0.n_pairs, out=kv_img))
+        kvf_ms = ev_ms(lambda: ops.kv_finalize_image(kv_part, b0.cloud_row0, b0.cloud_len, 0, 0, 2 * b0.n_pairs, 2 * b0.n_pairs, out=kv_img))
         k_corr = float(kab_call()[1].sum().item())
         nn_flop = 8.0 * sum(n * m for n, m in zip(b0.src_len, b0.tgt_len))                       # N M (3 fma + add + compare), SURVEY.md 8d
         nn_bytes = float(sum(12 * n + 12 * m + 9 * n for n, m in zip(b0.src_len, b0.tgt_len)))   # src_pred, tgt in; idx, dmin, valid out
@@ -559,7 +559,7 @@ def main():
                               "magnitude, not HBM-bound (SURVEY.md 8d); HIP events around back-to-back calls on the launch stream"}]
         secondary.append(hbm_row("pe_embed_ln_kernel (A1)", emb_ms, b0.rows_total * (12 + 1024.0),
                                  "12 B of coordinates in, 1 KB of features out per row; HIP events around back-to-back calls"))
-        secondary.append(hbm_row("kv_finalize_x3_kernel (A3 reduce, second stage; the stem's launch: every cloud of the batch)", kvf_ms,
+        secondary.append(hbm_row("kv_finalize_image_kernel (A3 reduce, second stage; the stem's launch: every cloud of the batch)", kvf_ms,
                                  kv_part.numel() * 4.0 + kv_img.numel(),
                                  "the K^T V partials of every 128-row tile in (33 KB per tile), one operand image per cloud out: 90 MB per "
                                  "launch behind a reduction whose depth is a cloud's ~40 tiles -- latency, not bandwidth"))

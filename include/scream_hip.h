@@ -134,7 +134,7 @@ int scream_gemm_qkv_split_f32(const float* A, int64_t lda, const void* W_packed,
  * q | k | v, the weights stream chunk by chunk (32 output columns over K = 256 = one 32 KiB stage) through a ring of LDS stages,
  * and every chunk's epilogue -- elu + 1 and the stores of a query chunk, or K' = elu(k) + 1, the operand split and K'^T V of a
  * head -- runs in the shadow of the NEXT chunk's matrix instructions.  Same arithmetic per product and the same outputs as
- * scream_gemm_qkv_split_f32 with SCREAM_LAYOUT_A_FRAG | SCREAM_LAYOUT_C_FRAG (Q' and the kv_partial array scream_kv_finalize_x3
+ * scream_gemm_qkv_split_f32 with SCREAM_LAYOUT_A_FRAG | SCREAM_LAYOUT_C_FRAG (Q' and the kv_partial array scream_kv_finalize_image
  * sums; the partial of a 128-row tile is added up from two 64-row halves instead of four 32-row quarters, so the two kernels
  * agree to fp32 rounding, not bit for bit).  The weight matrix W [N, 256] (row order of scream_gemm_qkv_f32 above: q | per
  * layer k 0-3 | v 0-3 | k 4-7 | v 4-7; n_q = 256 with N = 768, or n_q = 0 with N = 512 L) is packed once by scream_pack_proj
@@ -156,7 +156,7 @@ int scream_proj_qkv_f32(const float* x, const void* proj_image, float* Q, int64_
  * Q, x and y are FRAGMENT-major [M, 256] matrices (SCREAM_ACT_FRAG above; scream_act_layout converts):
  *   Q             the elu+1 mapped queries written by scream_gemm_qkv_split_f32 / scream_gemm_split_f32(EPI_ELU1) with
  *                 SCREAM_LAYOUT_C_FRAG;
- *   kv_image      scream_kv_image_bytes() per cloud, written by scream_kv_finalize_x3 from the K^T V partials of
+ *   kv_image      scream_kv_image_bytes() per cloud, written by scream_kv_finalize_image from the K^T V partials of
  *                 scream_gemm_qkv_split_f32 (same arguments as scream_kv_finalize): KV^T / S as MFMA operand fragments in
  *                 three bf16 planes + Ksum in fp32 (the apply runs on the bf16 x 3 split for either `split`: 3 % of the
  *                 kernel's matrix work, and KV is a data-dependent sum with no useful static bound);  the key cloud of 128-row
@@ -185,7 +185,7 @@ int scream_pack_tail(const float* Wm, const float* W1, const float* W2, const fl
 /* n_layers > 1: the partials of a batched key/value projection (scream_gemm_qkv_split_f32 with N = 512 n_layers): layer l
  * reads kv_partial + l * partial_layer_stride floats ((M/128) * 8 * 1056 of that GEMM) and writes its n_kv cloud images at
  * kv_image + l * image_layer_stride bytes.  n_layers == 1: strides ignored. */
-int scream_kv_finalize_x3(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
+int scream_kv_finalize_image(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
                           int64_t row_base, int32_t cloud_begin, int32_t n_kv, void* kv_image, int32_t n_layers,
                           int64_t partial_layer_stride, int64_t image_layer_stride, void* stream);
 int scream_layer_tail_f32(const float* Q, const void* kv_image, const int32_t* tile_cloud,

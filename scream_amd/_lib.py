@@ -68,7 +68,7 @@ SIGNATURES = {
     "scream_tail_image_bytes": (C.c_int64, [I32, I32]),
     "scream_kv_image_bytes": (C.c_int64, []),
     "scream_pack_tail": (C.c_int, [V, V, V, V, I32, C.POINTER(TailExpsT), V, V]),
-    "scream_kv_finalize_x3": (C.c_int, [V, V, V, I64, I32, I32, V, I32, I64, I64, V]),
+    "scream_kv_finalize_image": (C.c_int, [V, V, V, I64, I32, I32, V, I32, I64, I64, V]),
     "scream_layer_tail_f32": (C.c_int, [V, V, V, I32, V, V, V, V, V, V, V, V, V, I64, I32, C.POINTER(TailExpsT), V]),
     "scream_act_layout": (C.c_int, [V, V, I64, I32, V]),
     "scream_pe_embed_ln": (C.c_int, [V, V, V, V, V, V, V, V, V, I64, V]),

@@ -34,7 +34,10 @@ SOURCES = {
 EXTRA_DEFINES = {}
 for _item in filter(None, os.environ.get("SCREAM_HIPCC_EXTRA", "").split(";")):
     EXTRA_DEFINES[_item.split(":")[0]] = _item.split(":", 1)[1].split(",")
-ASM_LOADS = ("gemm_split.hip", "tail_split.hip")  # verified after code generation, see verify_one
+ASM_LOADS = ("gemm_split.hip", "tail_split.hip", "proj_ring.hip")  # verified after code generation, see verify_one
+# kernels that must not touch scratch at all: a spill inside a ring stage costs a round trip per stage, and hipcc orders a scratch
+# reload against the LDS-DMA in flight with vmcnt(0) -- the ring would drain once per stage (the layer tail's history)
+NO_SCRATCH = {"proj_ring.hip": ("proj_ring_kernel",), "tail_split.hip": ("tail_kernelINS_7SplitH2", "tail_kernelINS_7SplitH1")}
 
 
 def _hipcc() -> str:
@@ -89,6 +92,9 @@ def build(force: bool = False, verbose: bool = False, out: str = None) -> str:
         if r.returncode != 0:
             raise RuntimeError("hipcc -S failed for %s:\n%s" % (src, r.stderr))
         for name, body in chk.kernels(asm):
+            if any(k in name for k in NO_SCRATCH.get(src, ())) and any(("scratch_" in l or "buffer_store" in l) for l in body):
+                raise RuntimeError("%s: %s spills registers to scratch (this hipcc allocates registers differently from the one the "
+                                   "kernel was written with)" % (src, name))
             bad = chk.check_kernel(name, body)
             if bad:
                 raise RuntimeError("%s: %s touches a register whose asm load is still in flight (%d places, first: %s); "

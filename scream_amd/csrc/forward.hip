@@ -146,7 +146,7 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
     if (c.frag) {  // apply + merge + norm1 + FFN + norm2 in one launch
         {
             Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
-            TRY(scream_kv_finalize_x3(kvp, b.cloud_row0, b.cloud_len, row0, cloud_begin, n_clouds, w.kvimg, 1, 0, 0, c.st));
+            TRY(scream_kv_finalize_image(kvp, b.cloud_row0, b.cloud_len, row0, cloud_begin, n_clouds, w.kvimg, 1, 0, 0, c.st));
         }
         // merge (256) + FFN up and down (2 x 1024) (+ the next layer's query projection, 256) output columns per row
         Scope sc(c.tr, TR_TAIL_FUSED, rows, (next_q ? 10 : 9) * D, D, c.st);
@@ -176,7 +176,7 @@ int cross_kv_all(const Ctx& c, const scream_model_t& m, const scream_batch_t& b,
                  m.e_v_cross));
     Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
     // images are indexed by ABSOLUTE cloud (targets are clouds n_pairs .. 2 n_pairs - 1): layer l's block starts n_pairs images early
-    return scream_kv_finalize_x3(w.kvp_cross, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs,
+    return scream_kv_finalize_image(w.kvp_cross, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs,
                                  w.kvimg_cross - (int64_t)b.n_pairs * scream_kv_image_bytes(), m.n_cross, w.kvp_cross_stride,
                                  w.kvimg_cross_stride, c.st);
 }
@@ -201,7 +201,7 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
     if (c.frag) {
         {
             Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
-            TRY(scream_kv_finalize_x3(w.kvp, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs, w.kvimg, 1, 0, 0, c.st));
+            TRY(scream_kv_finalize_image(w.kvp, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs, w.kvimg, 1, 0, 0, c.st));
         }
         Scope sc(c.tr, TR_TAIL_FUSED, rs, 9 * D, D, c.st);
         return scream_layer_tail_f32(w.q, w.kvimg, b.tile_cloud, b.n_pairs, b.cloud_len, x_src, L.tail, L.g1, L.b1, L.g2, L.b2,

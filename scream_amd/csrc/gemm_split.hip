@@ -36,17 +36,17 @@
 //     the loop back edge and would wait for vmcnt(0) everywhere.  Counted waits are used only where nothing but loads
 //     is in flight; the first barrier of an output tile, behind the previous epilogue's stores, drains the queue.
 //   * The two waves of a SIMD are not symmetric: the older one gets the matrix pipe first (s_memtime stamps,
-//     tools/x3_stamps.py: 1.8 k cycles for its first 48 MFMAs against 3.8 k for the younger wave's), so the younger
+//     tools/gemm_stamps.py: 1.8 k cycles for its first 48 MFMAs against 3.8 k for the younger wave's), so the younger
 //     waves (4-7) do their operand split AFTER the barrier, where they would be starved anyway, the older ones before.
 //   * A dedicated 64 KiB LDS region holds the epilogue slabs, so the first k-tile of the next output tile is already
 //     in flight during the epilogue (for every epilogue kind).
-// What was measured and rejected on the way (tools/x3_ablate.py, tools/ubench/, profiles/r01_x3_ablation.txt): two
+// What was measured and rejected on the way (tools/gemm_ablate.py, tools/ubench/, profiles/r01_x3_ablation.txt): two
 // independent 128-row blocks per CU (doubles the W traffic; same speed), one wave per SIMD with 64-row wave tiles and
 // 512 registers (slower: a lone in-order wave does not keep the pipe full), spreading the fragment reads between the
 // MFMAs, starting the CUs out of phase, non-temporal stores.  On this chip a wave that issues MFMAs back to back
 // starves the LDS and vector-memory instructions of the other wave on its SIMD (not its VALU), which is why the
 // k-tile time is close to the SUM of the MFMA, LDS, VMEM and VALU issue times rather than their maximum.
-// Tuning aid (tools/x3_ablate.py builds variants): bit 0 no epilogue, 1 no W DMA after the first k-tile, 2 no A loads
+// Tuning aid (tools/gemm_ablate.py builds variants): bit 0 no epilogue, 1 no W DMA after the first k-tile, 2 no A loads
 // after the first, 3 no MFMAs, 4 no LDS fragment reads, 5 no operand split, 6 no epilogue stores, 7 no key/value-tile epilogue
 // (the fused K^T V reduce), 8 no query-tile epilogue (elu + 1 and the fragment-major stores).  Always 0 in libscream_hip.so.
 #ifndef X3_ABLATE
@@ -57,15 +57,15 @@
 #include "gemm_epilogue.h"
 #include "split.h"
 
-#ifdef X3_STAMPS  // tuning aid: s_memtime stamps of one output tile per block (tools/x3_stamps.py)
-__device__ long long x3_stamps[256 * 8 * 160];
-extern "C" int scream_x3_stamps_read(long long* host) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(x3_stamps), sizeof(long long) * 256 * 8 * 160);
+#ifdef X3_STAMPS  // tuning aid: s_memtime stamps of one output tile per block (tools/gemm_stamps.py)
+__device__ long long gemm_stamps[256 * 8 * 160];
+extern "C" int scream_gemm_stamps_read(long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gemm_stamps), sizeof(long long) * 256 * 8 * 160);
 }
 #define STAMP(slot)                                                                                    \
     do {                                                                                               \
         if (stamp_on && lane == 0 && (slot) < 160)                                                      \
-            x3_stamps[((int)blockIdx.x * 8 + wave) * 160 + (slot)] = __builtin_amdgcn_s_memtime();     \
+            gemm_stamps[((int)blockIdx.x * 8 + wave) * 160 + (slot)] = __builtin_amdgcn_s_memtime();     \
     } while (0)
 #else
 #define STAMP(slot) do {} while (0)
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void gemm_split_kernel(const float* __
             // Everything but the four youngest operations (A(kt+1)) has landed: W k-tile kt is in LDS for every wave
             // and every wave is done reading the other stage.  The first k-tile of an output tile drains everything:
             // the previous epilogue's STORES are in the queue there, and a counted wait is only sound among loads --
-            // stores complete out of order with respect to older loads (tools/x3_soak.py caught vmcnt(4 + #stores)
+            // stores complete out of order with respect to older loads (tools/gemm_soak.py caught vmcnt(4 + #stores)
             // returning with a load still in flight, once in ~10^8 tile boundaries).
             STAMP(4 + kt * 4 + 0);
             if (FIRST || TAIL == 2) ring_barrier<0>();

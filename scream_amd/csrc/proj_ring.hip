@@ -16,7 +16,7 @@
 //         the operand layout of a product whose contraction index is the ROW.  K' = elu(k) + 1 (padding rows zeroed) and V are
 //         split into fp16 planes straight from the accumulators and K'^T V of the wave's 64 rows is 12 MFMAs; the two waves
 //         of a 128-row tile add their tiles through 8 KiB of LDS in a fixed order and write the per-tile partial
-//         [head][33][32] that scream_kv_finalize_x3 sums per cloud.  K' and V never exist in memory.
+//         [head][33][32] that scream_kv_finalize_image sums per cloud.  K' and V never exist in memory.
 //     In the 8-wave GEMM a query tile's epilogue (a third of its time) ran with the matrix pipe idle -- its block-wide k-loop
 //     barriers keep both waves of a SIMD in lockstep.
 //     (Built first with LDS-DMA "touches" -- one dword per 128-byte line of the NEXT tile's rows, one instruction per stage -- to have
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
                 SplitH2::products(kv, kp[1][s2], vp[1], kv);
             }
         }
-        if (g == 9) kv *= pa.kv_inv;  // exact: a power of two (1 / v_length is applied once, in scream_kv_finalize_x3)
+        if (g == 9) kv *= pa.kv_inv;  // exact: a power of two (1 / v_length is applied once, in scream_kv_finalize_image)
         if (g >= 10 && g < 14) {
             float* sw = slabs + wave * P_KV_ELEMS;
 #pragma unroll

@@ -538,7 +538,11 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         auto stage_down = [&](V (&hin)[2][NP], V (&hout)[2][NP], auto with_split, auto xadd, auto ride, auto flush) {
             constexpr int XADD = decltype(xadd)::value;
             constexpr int RIDE = decltype(ride)::value;
+#ifdef T_PROBE_NOBAR  // TIMING PROBE ONLY (wrong results): the down stages wait for their pieces but skip the workgroup barrier
+            __builtin_amdgcn_s_waitcnt(0x0070 | (PIECES & 15) | ((PIECES >> 4) << 14));
+#else
             ring_barrier<PIECES>();
+#endif
             TMARK2(9, 11);  // ... and of the last two down stages
             __builtin_amdgcn_sched_barrier(0);
             if (XADD == 0) {  // the tile's first down stage starts the accumulators: tile 0 from its x segment, the others from 0
@@ -857,13 +861,13 @@ __global__ void pack_tail_kernel(const float* __restrict__ Wm, const float* __re
     for (int pl = 0; pl < SP::NP; ++pl) out[(((int64_t)stage * SP::NP + pl) * 16 + frag) * 64 + lane] = p[pl];
 }
 
-constexpr int KVF_THREADS = 320;  // kv_finalize_x3_kernel: 264 threads x 4 consecutive elements = the 1 056 of a head
+constexpr int KVF_THREADS = 320;  // kv_finalize_image_kernel: 264 threads x 4 consecutive elements = the 1 056 of a head
 
 // Sum of the per-128-row-tile K^T V partials of the fused q/k/v GEMM (as kv_finalize_tiles_kernel, attention.hip) written
 // as the operand image of tail_kernel: per cloud and head the A-operand fragments of KV_h^T / S (row m = value index
 // v, contraction index d = chunk_k(step, half, j)) in three bf16 planes, then Ksum as fp32.  grid (n_kv * 8, n_layers),
 // block KVF_THREADS; layer l reads partial + l * partial_layer_stride floats and writes kvimg + l * image_layer_stride bytes.
-__global__ __launch_bounds__(KVF_THREADS) void kv_finalize_x3_kernel(const float* __restrict__ partial,
+__global__ __launch_bounds__(KVF_THREADS) void kv_finalize_image_kernel(const float* __restrict__ partial,
                                                                    const int32_t* __restrict__ cloud_row0,
                                                                    const int32_t* __restrict__ cloud_len, int64_t row_base,
                                                                    int cloud_begin, char* __restrict__ kvimg,
@@ -969,7 +973,7 @@ extern "C" int scream_pack_tail(const float* Wm, const float* W1, const float* W
     return 0;
 }
 
-extern "C" int scream_kv_finalize_x3(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
+extern "C" int scream_kv_finalize_image(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
                                      int64_t row_base, int32_t cloud_begin, int32_t n_kv, void* kv_image, int32_t n_layers,
                                      int64_t partial_layer_stride, int64_t image_layer_stride, void* stream) {
     SCREAM_REQUIRE(kv_partial && cloud_row0 && cloud_len && kv_image, SCREAM_EINVAL);
@@ -978,7 +982,7 @@ extern "C" int scream_kv_finalize_x3(const float* kv_partial, const int32_t* clo
     SCREAM_REQUIRE(((reinterpret_cast<uintptr_t>(kv_image) | reinterpret_cast<uintptr_t>(kv_partial)) & 15) == 0 && partial_layer_stride % 4 == 0,
                    SCREAM_EINVAL);
     if (n_kv == 0) return 0;
-    kv_finalize_x3_kernel<<<dim3(n_kv * SCREAM_NHEAD, n_layers), dim3(KVF_THREADS), 0, as_stream(stream)>>>(
+    kv_finalize_image_kernel<<<dim3(n_kv * SCREAM_NHEAD, n_layers), dim3(KVF_THREADS), 0, as_stream(stream)>>>(
         kv_partial, cloud_row0, cloud_len, row_base, cloud_begin, reinterpret_cast<char*>(kv_image), partial_layer_stride, image_layer_stride);
     SCREAM_LAUNCH_CHECK();
     return 0;

@@ -171,7 +171,7 @@ def pack_tail(Wm: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, split: Optio
     return PackedTail(out, split, exps, Wq_next is not None)
 
 
-def kv_finalize_x3(partial: torch.Tensor, cloud_row0, cloud_len, row_base: int, cloud_begin: int, n_kv: int,
+def kv_finalize_image(partial: torch.Tensor, cloud_row0, cloud_len, row_base: int, cloud_begin: int, n_kv: int,
                    n_clouds: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """K^T V partials of gemm_qkv -> the per-cloud operand image of layer_tail ([n_clouds, kv_image_bytes] uint8).
     partial [L, M/128, 8, 1056] (a batched key/value projection of L layers): returns [L, n_clouds, kv_image_bytes]."""
@@ -180,9 +180,9 @@ def kv_finalize_x3(partial: torch.Tensor, cloud_row0, cloud_len, row_base: int, 
     img = lib.scream_kv_image_bytes()
     if out is None:
         out = torch.zeros((L, n_clouds, img) if partial.dim() == 4 else (n_clouds, img), device=partial.device, dtype=torch.uint8)
-    check(lib.scream_kv_finalize_x3(_p(partial), _p(cloud_row0, torch.int32), _p(cloud_len, torch.int32), row_base,
+    check(lib.scream_kv_finalize_image(_p(partial), _p(cloud_row0, torch.int32), _p(cloud_len, torch.int32), row_base,
                                     cloud_begin, n_kv, _p(out, torch.uint8), L, partial[0].numel() if L > 1 else 0,
-                                    n_clouds * img if L > 1 else 0, _stream()), "scream_kv_finalize_x3")
+                                    n_clouds * img if L > 1 else 0, _stream()), "scream_kv_finalize_image")
     return out
 
 

@@ -397,7 +397,7 @@ def test_batched_key_value_projection_of_several_layers_equals_one_launch_per_la
     """scream_gemm_qkv_split_f32 with N = 512 L, n_q == 0 (the cross stage's target side: the target features are frozen after
     the stem, models/pointnet.py:53-57, so the L cross layers' key/value projections read the SAME rows): the partials of
     layer l, at kv_partial + l (M/128) 8 1056, are bit for bit those of that layer's own N = 512 launch (same exponents), and
-    one scream_kv_finalize_x3 launch over all layers writes the same images as L launches."""
+    one scream_kv_finalize_image launch over all layers writes the same images as L launches."""
     g = torch.Generator().manual_seed(17)
     L, lens, row0, rows, base = 3, [300, 129, 700], [0, 384, 640], 1408, 256
     x = torch.randn(base + rows, 256, generator=g)
@@ -410,11 +410,11 @@ def test_batched_key_value_projection_of_several_layers_equals_one_launch_per_la
     xd = dev(x[base:].clamp(-8, 8))
     _, part_all = ops.gemm_qkv(xd, ops.pack_w(dev(torch.cat(Ws)), SPL, w_exp), 0, tiles, crow0, clen, base, a_exp=a_exp)
     assert part_all.shape == (L, rows // 128, 8, 1056)
-    img_all = ops.kv_finalize_x3(part_all, crow0, clen, base, 0, 3, 3)
+    img_all = ops.kv_finalize_image(part_all, crow0, clen, base, 0, 3, 3)
     for l in range(L):
         _, part = ops.gemm_qkv(xd, ops.pack_w(dev(Ws[l]), SPL, w_exp), 0, tiles, crow0, clen, base, a_exp=a_exp)
         assert torch.equal(part, part_all[l])
-        assert torch.equal(ops.kv_finalize_x3(part, crow0, clen, base, 0, 3, 3), img_all[l])
+        assert torch.equal(ops.kv_finalize_image(part, crow0, clen, base, 0, 3, 3), img_all[l])
 
 
 @pytest.mark.parametrize("backend", ["h2", "x3"])
@@ -710,12 +710,12 @@ def test_gemm_split_persistent_blocks_many_tiles(epi, split):
 
 
 def test_gemm_split_two_stream_soak_short():
-    """Six seconds of tools/x3_soak.py: random shapes and epilogues of the split GEMM (both splits) against the fp32-MFMA GEMM on two
+    """Six seconds of tools/gemm_soak.py: random shapes and epilogues of the split GEMM (both splits) against the fp32-MFMA GEMM on two
     HIP streams at once (the lanes configuration).  The long form of this test is what caught a counted wait that was
     unsound across the epilogue's stores (once in ~10^5 launches); the short form guards against coarser mistakes."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "x3_soak.py"), "6", "3"], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_soak.py"), "6", "3"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -816,7 +816,7 @@ def test_kabsch_round_trip_at_65536_correspondences():
 @pytest.mark.parametrize("cross", [False, True])
 def test_fused_layer_tail_vs_oracle_block(cross, split):
     """One whole MHAttention block (models/transformer.py:74-90) on the fused path: q/k/v projection GEMM (K^T V in its
-    epilogue) -> scream_kv_finalize_x3 -> scream_layer_tail_f32 (apply, merge + norm1, FFN + norm2 in ONE launch; att,
+    epilogue) -> scream_kv_finalize_image -> scream_layer_tail_f32 (apply, merge + norm1, FFN + norm2 in ONE launch; att,
     m1 and the hidden activations never reach memory) against the oracle block, on ragged clouds with padding rows, for
     a self block (three clouds, several row tiles per block) and a cross block (queries and keys from different clouds)."""
     sd = make_state_dict(21, 256, 1, 1)
@@ -855,7 +855,7 @@ def test_fused_layer_tail_vs_oracle_block(cross, split):
         else:
             torch.testing.assert_close(ops.act_layout(Q, False), Qr, rtol=2e-6, atol=2e-6)
         assert torch.equal(part, part_r)
-        kvi = ops.kv_finalize_x3(part, crow0, clen, 0, 0, 3, 3)
+        kvi = ops.kv_finalize_image(part, crow0, clen, 0, 0, 3, 3)
         y = ops.act_layout(ops.layer_tail(Q, kvi, dev(tiles), 0, clen, xf, img, g1, b1, g2, b2), False).cpu()
         for r0, xc in zip(row0, xs):
             want = O.mh_attention(xc[None], xc[None], xc[None], sd, pre)[0]
@@ -864,7 +864,7 @@ def test_fused_layer_tail_vs_oracle_block(cross, split):
         # queries: cloud 0 (rows 0..383); keys/values: cloud 2 (rows 640..) -- "source attends to target", kv_cloud_offset 2
         Q = ops.gemm_split(xf[:384], pk(q), ops.EPI_ELU1, n_act=256, layout=FR)
         _, part = ops.gemm_qkv(xf[640:], pk(Wkv), 0, dev(tiles), crow0, clen, 640, ops.LAYOUT_A_FRAG)
-        kvi = ops.kv_finalize_x3(part, crow0, clen, 640, 2, 1, 3)
+        kvi = ops.kv_finalize_image(part, crow0, clen, 640, 2, 1, 3)
         y = ops.act_layout(ops.layer_tail(Q, kvi, dev(tiles[:3].contiguous()), 2, clen, xf[:384], img, g1, b1, g2, b2), False).cpu()
         want = O.mh_attention(xs[0][None], xs[2][None], xs[2][None], sd, pre)[0]
         torch.testing.assert_close(y[:300], want, rtol=2e-4, atol=5e-5)
@@ -900,7 +900,7 @@ def test_fused_layer_tail_many_tiles_equals_unfused_path(split):
     Q = ops.act_layout(Qf, False)
     ex = tail_exps_for(sd, pre, float((x @ v.t()).abs().max()) * 1.01)
     img = ops.pack_tail(dev(sd[pre + "merge.weight"]), dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"]), SPL, ex)
-    kvi = ops.kv_finalize_x3(part, crow0, clen, 0, 0, n_clouds, n_clouds)
+    kvi = ops.kv_finalize_image(part, crow0, clen, 0, 0, n_clouds, n_clouds)
     yf = ops.layer_tail(Qf, kvi, tc, 0, clen, xf, img, g1, b1, g2, b2)
     y = ops.act_layout(yf, False)
     kv = ops.kv_finalize(part, crow0, clen, 0, 0, n_clouds, n_clouds)
@@ -940,7 +940,7 @@ def test_layer_tail_with_the_next_layers_query_projection():
     xf = ops.act_layout(dev(x), True)
     SPL = ops.SPLIT_H2
     Qf, part = ops.gemm_qkv(xf, ops.pack_w(dev(W), SPL), 256, tc, crow0, clen, 0, ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG)
-    kvi = ops.kv_finalize_x3(part, crow0, clen, 0, 0, n_clouds, n_clouds)
+    kvi = ops.kv_finalize_image(part, crow0, clen, 0, 0, n_clouds, n_clouds)
     exd = scales.tail_exps(sd[pre + "merge.weight"], sd[pre + "mlp.0.weight"], sd[pre + "mlp.2.weight"], sd[pre + "norm1.weight"],
                            sd[pre + "norm1.bias"], float((x @ v.t()).abs().max()) * 1.01)
     plain = ops.pack_tail(dev(sd[pre + "merge.weight"]), dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"]), SPL, ops.tail_exps(**exd))

@@ -507,7 +507,7 @@ def test_the_static_checker_detects_what_it_is_there_for():
 
 
 def test_tuning_builds_are_verified_before_they_can_be_launched(tmp_path):
-    """tools/tail_ablate.py / tail_stamps.py / x3_ablate.py / x3_stamps.py compile -D variants of the two hand-scheduled kernels;
+    """tools/tail_ablate.py / tail_stamps.py / gemm_ablate.py / gemm_stamps.py compile -D variants of the two hand-scheduled kernels;
     every variant goes through asm_inflight_check.verify_source first (round 2 launched an unverified one and faulted the GPU).
     The "no weight DMA" variant of the fp16 layer tail -- the variant that faulted, now with draining waits -- passes; a
     variant in which hipcc moves a pending register raises instead of producing a library."""
@@ -636,3 +636,29 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["ranks"] == [0, 1] and out["steps"] == 4
     r = subprocess.run(cmd, env=dict(base, SCREAM_BENCH_DRY_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 3 and not r.stdout.strip()
+
+
+def test_ring_projection_kernel_keeps_its_registers(tmp_path):
+    """csrc/proj_ring.hip holds the operand planes of a wave's 64 rows in the WHOLE accumulation register file (256 AGPRs, pinned
+    with "+a" constraints) and its accumulators in VGPRs (-mllvm -amdgpu-mfma-vgpr-form=1, scream_amd/build.py): the generated code
+    must have no scratch, and the only moves between the two register files are the 256 writes per tile that park the freshly split
+    planes -- left to itself hipcc keeps the planes VGPR-class and moves each one back in front of every matrix instruction
+    (1 141 moves, a quarter of the kernel's vector instructions, when the kernel was first built)."""
+    import re, shutil, subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    from scream_amd import build as B
+    src = os.path.join(REPO, "scream_amd", "csrc", "proj_ring.hip")
+    out = tmp_path / "ring.s"
+    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", *B.SOURCES["proj_ring.hip"], "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, capture_output=True, timeout=600)
+    text = out.read_text()
+    m = re.search(r"^(\S*proj_ring_kernelINS_7SplitH2\S*):[^\n]*\n(.*?)\.Lfunc_end", text, re.S | re.M)
+    assert m, "proj_ring_kernel<SplitH2> not found"
+    body = m.group(2)
+    assert "scratch_" not in body
+    assert len(re.findall(r"v_accvgpr_write", body)) == 256 and len(re.findall(r"v_accvgpr_read", body)) == 0
+    assert len(re.findall(r"v_mfma_f32_32x32x16_f16 v\[", body)) == len(re.findall(r"v_mfma_f32_32x32x16_f16", body))  # accumulators in VGPRs
+    meta = text[text.index("amdhsa.kernels"):]
+    k = meta[meta.index("proj_ring_kernelINS_7SplitH2") - 400: meta.index("proj_ring_kernelINS_7SplitH2") + 400]
+    assert ".private_segment_fixed_size: 0" in k and ".vgpr_spill_count: 0" in k

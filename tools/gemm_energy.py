@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Energy per launch of the ablation variants of gemm_split_kernel (X3_SPLIT=h2 | x3) (tools/x3_ablate.py build first): rocm-smi power and
+"""Energy per launch of the ablation variants of gemm_split_kernel (X3_SPLIT=h2 | x3) (tools/gemm_ablate.py build first): rocm-smi power and
 sclk sampled while each variant runs for ~2.5 s on the FFN 256->1024 shape.  Under the 1400 W cap, time follows energy."""
 import ctypes, os, re, subprocess, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import torch
 from scream_amd import ops
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-import x3_ablate
+import gemm_ablate
 import _split_ctypes as SC
 dev = "cuda:0"; M = 327680
 shape = os.environ.get("X3_SHAPE", "ffn1")
@@ -26,7 +26,7 @@ def sampler():
 th = threading.Thread(target=sampler, daemon=True); th.start()  # (daemon: a traceback in the main thread must end the process)
 tag = os.environ.get("X3_TAG", "")
 print("%-28s %9s %9s %9s %10s   (%s, M=%d; idle power ~296 W)" % ("variant", "ms", "sclk MHz", "power W", "J/launch", shape, M))
-for bits, label in x3_ablate.VARIANTS:
+for bits, label in gemm_ablate.VARIANTS:
     f = os.path.join(ROOT, "tools", "_abl" + tag, "x3_%d.so" % bits)
     if not os.path.exists(f): continue
     lib, pack, gemm = SC.bind(f)

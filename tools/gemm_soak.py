@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak test: the split GEMM (a random one of its two operand splits per draw: 2 x fp16 / 3 x bf16) against the fp32-MFMA GEMM
 on random (M, epilogue) draws for a fixed wall time, on two streams at once (the lanes configuration).  A mismatch is re-checked against torch on the default stream to tell
-which kernel is off.  usage: x3_soak.py [seconds]"""
+which kernel is off.  usage: gemm_soak.py [seconds]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-kernel s_memtime stamps of gemm_split_kernel (X3_SPLIT=h2 | x3; third output tile of every block): where a k-tile's time goes.
-   build: hipcc ... -DX3_STAMPS -> tools/_abl_stamps/x3_0.so (python tools/x3_stamps.py build);  run on the GPU."""
+   build: hipcc ... -DX3_STAMPS -> tools/_abl_stamps/x3_0.so (python tools/gemm_stamps.py build);  run on the GPU."""
 import ctypes, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,7 +29,7 @@ for name, N, K, epi in [("ffn1", 1024, 256, ops.EPI_RELU), ("merge", 256, 256, o
         assert gemm(A, Wp, w_exp, o, M, N, K, epi, 0, r, gam, st) == 0
     torch.cuda.synchronize()
     buf = np.zeros(256 * 8 * 160, dtype=np.int64)
-    assert lib.scream_x3_stamps_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert lib.scream_gemm_stamps_read(buf.ctypes.data_as(ctypes.c_void_p)) == 0
     s = buf.reshape(256, 8, 160).astype(np.float64)
     KT = K // 32
     t0 = s[:, :, 0:1]

@@ -4,7 +4,7 @@ transposed query tile stored fragment-major, fused K^T V reduce on the key/value
 per launch of every -DX3_ABLATE variant of scream_amd/csrc/gemm_split.hip, on the two shapes of a step:
     stem     M = 333 184 rows, N = 768  (q | k,v heads 0-3 | k,v heads 4-7)
     crosskv  M = 166 912 rows, N = 3072 (the six cross layers' target-side key/value projections, no queries)
-`build` on the CPU box (every variant goes through tools/asm_inflight_check.py first, as in x3_ablate.py), `run` on the GPU.
+`build` on the CPU box (every variant goes through tools/asm_inflight_check.py first, as in gemm_ablate.py), `run` on the GPU.
 P_SRC=<file> selects another source with the same entry points (a candidate kernel), P_TAG its output directory suffix."""
 import ctypes, os, re, subprocess, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -47,7 +47,7 @@ while time.time() - t0 < secs:
             p = P[(ops.SPLIT_H2, ops.SPLIT_BF3, ops.SPLIT_H2)[kind]]
             img = p["img"]
             Qf, part = ops.gemm_qkv(xf, p["q"], 256, tc, cr, cl, 0, FR, a_exp=A_EXP)
-            kvi = ops.kv_finalize_x3(part, cr, cl, 0, 0, n_clouds, n_clouds)
+            kvi = ops.kv_finalize_image(part, cr, cl, 0, 0, n_clouds, n_clouds)
             if kind == 2:
                 qa, qb = Qf.clone(), Qf.clone()
                 y1 = ops.layer_tail(qa, kvi, tc, 0, cl, xf, IMG_Q, g1, b1, g2, b2, q_next=qa)

@@ -44,7 +44,7 @@ def run():
     ft = lib.scream_layer_tail_f32; ft.restype = ctypes.c_int
     ft.argtypes = [V, V, V, I32, V, V, V, V, V, V, V, V, V, I64, I32, ctypes.POINTER(_lib.TailExpsT), V]
     pt = lib.scream_pack_tail; pt.restype = ctypes.c_int; pt.argtypes = [V, V, V, V, I32, ctypes.POINTER(_lib.TailExpsT), V, V]
-    kf = lib.scream_kv_finalize_x3; kf.restype = ctypes.c_int; kf.argtypes = [V, V, V, I64, I32, I32, V, I32, I64, I64, V]
+    kf = lib.scream_kv_finalize_image; kf.restype = ctypes.c_int; kf.argtypes = [V, V, V, I64, I32, I32, V, I32, I64, I64, V]
     tb = lib.scream_tail_image_bytes; tb.restype = ctypes.c_int64; tb.argtypes = [I32, I32]
     st = torch.cuda.current_stream().cuda_stream
     timg = torch.empty(tb(split, 0), device=dev, dtype=torch.uint8)
