@@ -157,9 +157,9 @@ int scream_proj_qkv_f32(const float* x, const void* proj_image, float* Q, int64_
  *   Q             the elu+1 mapped queries written by scream_gemm_qkv_split_f32 / scream_gemm_split_f32(EPI_ELU1) with
  *                 SCREAM_LAYOUT_C_FRAG;
  *   kv_image      scream_kv_image_bytes() per cloud, written by scream_kv_finalize_image from the K^T V partials of
- *                 scream_gemm_qkv_split_f32 (same arguments as scream_kv_finalize): KV^T / S as MFMA operand fragments in
- *                 three bf16 planes + Ksum in fp32 (the apply runs on the bf16 x 3 split for either `split`: 3 % of the
- *                 kernel's matrix work, and KV is a data-dependent sum with no useful static bound);  the key cloud of 128-row
+ *                 scream_gemm_qkv_split_f32 (same arguments as scream_kv_finalize): KV^T / S as MFMA operand fragments + Ksum in fp32, for the SAME `split` as the tail that reads it: three bf16 planes
+ *                 (SCREAM_SPLIT_BF3) or -- fp16 splits, round 4 -- two fp16 planes of KV_h^T / S * 2^e_h, e_h chosen on the device from the
+ *                 head's largest |element| (a maximum: exact, order independent) with 2^-e_h stored beside them;  the key cloud of 128-row
  *                 tile t is tile_cloud[t] + kv_cloud_offset (tile_cloud points at the entry of the first row), cloud_len gives S;
  *   x             the block input (residual of BOTH norms), must not alias y;
  *   tail_image    scream_tail_image_bytes(split), built once by scream_pack_tail from merge [256,256], mlp.0 [1024,256]
@@ -173,6 +173,8 @@ int scream_proj_qkv_f32(const float* x, const void* proj_image, float* Q, int64_
 typedef struct {
     int32_t e_att, e_wm, e_m1, e_w1, e_h, e_w2;
     int32_t e_y, e_wq; /* only with a next-layer query projection in the image (below): of the block output y and of that Wq */
+    int32_t e_q;       /* of Q' = elu(q) + 1 as an operand of the attention apply (fp16 x 2 since round 4): |Q'| 2^e_q <= 2^15, Q' <= 1 + the
+                        * bound of the query projection (scream_amd/scales.py: 16 |w * gamma|_2 + |w . beta| over the rows of Wq) */
 } scream_tail_exps_t;
 int64_t scream_tail_image_bytes(int32_t split, int32_t with_next_q);
 int64_t scream_kv_image_bytes(void);
@@ -187,7 +189,7 @@ int scream_pack_tail(const float* Wm, const float* W1, const float* W2, const fl
  * kv_image + l * image_layer_stride bytes.  n_layers == 1: strides ignored. */
 int scream_kv_finalize_image(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
                           int64_t row_base, int32_t cloud_begin, int32_t n_kv, void* kv_image, int32_t n_layers,
-                          int64_t partial_layer_stride, int64_t image_layer_stride, void* stream);
+                          int64_t partial_layer_stride, int64_t image_layer_stride, int32_t split, void* stream);
 int scream_layer_tail_f32(const float* Q, const void* kv_image, const int32_t* tile_cloud,
                           int32_t kv_cloud_offset, const int32_t* cloud_len, const float* x,
                           const void* tail_image, const float* g1, const float* b1, const float* g2,

@@ -146,7 +146,7 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
     if (c.frag) {  // apply + merge + norm1 + FFN + norm2 in one launch
         {
             Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
-            TRY(scream_kv_finalize_image(kvp, b.cloud_row0, b.cloud_len, row0, cloud_begin, n_clouds, w.kvimg, 1, 0, 0, c.st));
+            TRY(scream_kv_finalize_image(kvp, b.cloud_row0, b.cloud_len, row0, cloud_begin, n_clouds, w.kvimg, 1, 0, 0, c.split, c.st));
         }
         // merge (256) + FFN up and down (2 x 1024) (+ the next layer's query projection, 256) output columns per row
         Scope sc(c.tr, TR_TAIL_FUSED, rows, (next_q ? 10 : 9) * D, D, c.st);
@@ -178,7 +178,7 @@ int cross_kv_all(const Ctx& c, const scream_model_t& m, const scream_batch_t& b,
     // images are indexed by ABSOLUTE cloud (targets are clouds n_pairs .. 2 n_pairs - 1): layer l's block starts n_pairs images early
     return scream_kv_finalize_image(w.kvp_cross, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs,
                                  w.kvimg_cross - (int64_t)b.n_pairs * scream_kv_image_bytes(), m.n_cross, w.kvp_cross_stride,
-                                 w.kvimg_cross_stride, c.st);
+                                 w.kvimg_cross_stride, c.split, c.st);
 }
 
 // Cross attention: queries from the source rows, keys/values from the frozen target rows (transformer.py:130).
@@ -201,7 +201,7 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
     if (c.frag) {
         {
             Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
-            TRY(scream_kv_finalize_image(w.kvp, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs, w.kvimg, 1, 0, 0, c.st));
+            TRY(scream_kv_finalize_image(w.kvp, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs, w.kvimg, 1, 0, 0, c.split, c.st));
         }
         Scope sc(c.tr, TR_TAIL_FUSED, rs, 9 * D, D, c.st);
         return scream_layer_tail_f32(w.q, w.kvimg, b.tile_cloud, b.n_pairs, b.cloud_len, x_src, L.tail, L.g1, L.b1, L.g2, L.b2,
@@ -220,8 +220,8 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
 
 }  // namespace
 
-extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi16"; }
-extern "C" int scream_abi_version(void) { return 16; }
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi17"; }
+extern "C" int scream_abi_version(void) { return 17; }
 
 extern "C" void* scream_trace_create(int32_t capacity) {
     if (capacity <= 0) return nullptr;

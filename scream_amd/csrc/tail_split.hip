@@ -103,14 +103,27 @@ constexpr int NEXT_Q_STAGES = 8;  // tail_kernel<SP, true>: the NEXT layer's 256
 constexpr int KV_PLANES_BYTES = 8 * 3 * 2 * 1024;            // per cloud: [head][plane][step][lane][8] bf16
 constexpr int KV_IMAGE_BYTES = KV_PLANES_BYTES + 8 * 32 * 4;  // + Ksum [head][32] fp32
 
+// fp16 splits (round 4, T_APPLY_H2): the apply runs on fp16 x 2 as well.  The image then holds, per head, KV_h^T / S * 2^e_h in TWO fp16
+// planes ([head][plane][step][lane][8], 4 KiB per head) with e_h the largest exponent that keeps the head's largest |element| at or
+// below 2^15 -- computed on the device by kv_finalize_image_kernel from the reduced sum itself (a maximum: exact and independent of
+// any order, so batched == single pair stays bitwise) -- and 2^-e_h eight times over in the 32 bytes of head h at KV_H2_SCALE_OFF.
+constexpr int KV_H2_HEAD_BYTES = 2 * 2 * 1024;
+constexpr int KV_H2_SCALE_OFF = 8 * KV_H2_HEAD_BYTES;  // 32 KiB: inside the plane area the bf16 layout fills, unused by this one
+#ifndef T_APPLY_H2
+#define T_APPLY_H2 1  // 0: the attention apply of the fp16 kernels stays on bf16 x 3 (rounds 2-3)
+#endif
+
 struct HeadOps {   // the per-cloud operands of one head's apply, as loaded (Q' travels separately: f32x4 q[4], pieces a = 0 .. 3)
-    f32x4 kv[6];   // KV_h^T fragments [plane][step], 16 bytes per lane
+    f32x4 kv[6];   // KV_h^T fragments [plane][step], 16 bytes per lane (fp16 x 2: four of them)
     f32x4 ks[4];   // Ksum[h][8 a + 4 half .. + 4]
+    f32x4 sc;      // fp16 x 2: 2^-e_h in every element
 };
 
 // SplitH2: the exact power-of-two factors of the kernel (all 1 / unused for SplitBf3)
 struct TailScales {
     float s_att;  // 2^e_att, folded into Z
+    float s_q;    // fp16 x 2 apply: 2^e_q, the scale of Q' = elu(q) + 1 <= 1 + the bound of q as an operand
+    float s_attq; // 2^(e_att - e_q): with the head's 2^-e_h what takes the apply's accumulator to the scaled attention output
     float c1;     // 2^(e_wm + e_att): unit of the merge accumulators
     float eps1;   // 1e-5 c1^2
     float s_m1;   // 2^e_m1, folded into gamma1 / beta1
@@ -155,6 +168,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
     constexpr int NP = SP::NP;
     constexpr int STAGE = stage_bytes<SP>();
     constexpr int PIECES = wave_pieces<SP>();  // LDS-DMA pieces per wave and stage = what a counted ring wait leaves in flight
+    constexpr bool APPLY_H2 = SP::SCALED && T_APPLY_H2;  // the attention apply on fp16 x 2 planes (image written by kv_finalize_image in that form)
 #ifdef T_NV_MERGE  // tuning aid (tools/tail_stamps.py, T_EXTRA): another ride-slot count
     constexpr int NV_MERGE = T_NV_MERGE;
 #else
@@ -208,10 +222,15 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
     };
     auto req_head = [&](HeadOps& o, const char* kvc, int h) {  // KV^T fragments and Ksum of head h: L2-hot per-cloud data
         if (T_ABLATE & (16 | 256)) return;
-        const char* kp = kvc + h * (3 * 2 * 1024);
         f32x4 (&kv4)[4] = reinterpret_cast<f32x4 (&)[4]>(o.kv[0]);
-        ld_asm4<1024>(kv4, kp, v_lane16);
-        ld_asm2k(o.kv[4], o.kv[5], kp + 4 * 1024, v_lane16);
+        if (APPLY_H2) {
+            ld_asm4<1024>(kv4, kvc + h * KV_H2_HEAD_BYTES, v_lane16);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(o.sc) : "v"(v_half16), "s"(kvc + KV_H2_SCALE_OFF + 32 * h));
+        } else {
+            const char* kp = kvc + h * (3 * 2 * 1024);
+            ld_asm4<1024>(kv4, kp, v_lane16);
+            ld_asm2k(o.kv[4], o.kv[5], kp + 4 * 1024, v_lane16);
+        }
         ld_asm4<32>(o.ks, kvc + KV_PLANES_BYTES + 128 * h, v_half16);
     };
     auto req_x = [&](f32x4 (&xs)[4], int64_t grp, int blk) {
@@ -223,7 +242,8 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
 #pragma unroll
         for (int a = 0; a < 4; ++a) pin(o.ks[a]);
 #pragma unroll
-        for (int f = 0; f < 6; ++f) pin(o.kv[f]);
+        for (int f = 0; f < (APPLY_H2 ? 4 : 6); ++f) pin(o.kv[f]);
+        if (APPLY_H2) pin(o.sc);
     };
     // the residual x joins an accumulator tile: plain add, or (SplitH2) fma with the tile's unit c
     auto add_x4 = [&](f32x16& t, const f32x4 (&xs)[4], int a, float c) {  // one quarter (registers 4a .. 4a + 3)
@@ -251,23 +271,29 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
     f32x4 xs[4], xs2[4];    // x segments (xs2: only segment 7 of the norm1 residual)
     V apA[2][NP], apB[2][NP];  // planes of att_h^T, the B operand of the merge GEMM: heads of even / odd index
     f32x16 aT;              // att_h^T tile of the head being applied
-    bf16x8 qp[2][3];        // the apply runs on SplitBf3 in both instantiations
+    bf16x8 qp[2][3];        // bf16 x 3 apply (SplitBf3 kernels; the fp16 kernels with T_APPLY_H2 = 0)
+    f16x8 qph[2][2];        // fp16 x 2 apply: the planes of Q' 2^e_q
     float Zs = 0.f;
 
     // ---- apply of one head (models/transformer.py:41-42), in pieces that ride inside the groups of another stage ----
-    auto apply_qsplit = [&](f32x4 (&qb)[4], int tile_tag, int s2) {  // 16-deep step s2 of Q' into its three planes
-        if (T_ABLATE & 16) {
-            const f32x4 f = {(float)lane, 1.0f, 0.5f, (float)tile_tag};
-            split8<SplitBf3>(f, f, qp[s2]);
-            return;
-        }
-        split8<SplitBf3>(qb[2 * s2], qb[2 * s2 + 1], qp[s2]);
+    auto apply_qsplit = [&](f32x4 (&qb)[4], int tile_tag, int s2) {  // 16-deep step s2 of Q' into its planes
+        f32x4 lo = qb[2 * s2], hi = qb[2 * s2 + 1];
+        if (T_ABLATE & 16) lo = hi = f32x4{(float)lane, 1.0f, 0.5f, (float)tile_tag};
+        if (APPLY_H2) split8s<SplitH2>(lo, hi, sc.s_q, qph[s2]);
+        else split8<SplitBf3>(lo, hi, qp[s2]);
     };
     auto apply_mfma = [&](int s2) {
-        bf16x8 w[3];
+        if (APPLY_H2) {
+            f16x8 w[2];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) w[p] = __builtin_bit_cast(bf16x8, op.kv[p * 2 + s2]);
-        mfma_group<SplitBf3, -1>(aT, w, qp[s2], s2 == 0);
+            for (int p = 0; p < 2; ++p) w[p] = __builtin_bit_cast(f16x8, op.kv[p * 2 + s2]);
+            mfma_group<SplitH2, -1>(aT, w, qph[s2], s2 == 0);
+        } else {
+            bf16x8 w[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) w[p] = __builtin_bit_cast(bf16x8, op.kv[p * 2 + s2]);
+            mfma_group<SplitBf3, -1>(aT, w, qp[s2], s2 == 0);
+        }
     };
     auto apply_z = [&](f32x4 (&qb)[4]) {  // Z = 1 / (Q'.Ksum + 1e-6); lanes r and r + 32 share row r
         float zp = 0.f;
@@ -277,7 +303,10 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
             for (int k = 0; k < 4; ++k) zp += qb[a][k] * op.ks[a][k];
         zp += __shfl_xor(zp, 32);
         Zs = 1.0f / (zp + 1e-6f);
-        if (SP::SCALED) Zs *= sc.s_att;  // exact; (aT * (Z 2^e)) * S == ((aT * Z) * S) 2^e bit for bit
+        // exact powers of two: (aT * (Z 2^e)) * S == ((aT * Z) * S) 2^e bit for bit; the fp16 x 2 apply's accumulator is in units of
+        // 2^(e_h + e_q), so its Z also carries 2^-(e_h + e_q)
+        if (APPLY_H2) Zs *= sc.s_attq * op.sc[0];
+        else if (SP::SCALED) Zs *= sc.s_att;
     };
     auto apply_split_pair = [&](int k, V (&ap)[2][NP], float S) {  // elements 2k, 2k+1: (aT * Z) * S, then the operand split
         const int s2 = k >> 2, j = (2 * k) & 7;
@@ -863,59 +892,95 @@ __global__ void pack_tail_kernel(const float* __restrict__ Wm, const float* __re
 
 constexpr int KVF_THREADS = 320;  // kv_finalize_image_kernel: 264 threads x 4 consecutive elements = the 1 056 of a head
 
-// Sum of the per-128-row-tile K^T V partials of the fused q/k/v GEMM (as kv_finalize_tiles_kernel, attention.hip) written
+// Sum of the per-128-row-tile K^T V partials of the fused q/k/v projection (as kv_finalize_tiles_kernel, attention.hip) written
 // as the operand image of tail_kernel: per cloud and head the A-operand fragments of KV_h^T / S (row m = value index
-// v, contraction index d = chunk_k(step, half, j)) in three bf16 planes, then Ksum as fp32.  grid (n_kv * 8, n_layers),
-// block KVF_THREADS; layer l reads partial + l * partial_layer_stride floats and writes kvimg + l * image_layer_stride bytes.
+// v, contraction index d = chunk_k(step, half, j)), then Ksum as fp32.  H2 = false: three bf16 planes (exact split, no scale).
+// H2 = true (round 4): two fp16 planes of KV_h^T / S * 2^e_h, e_h from the head's largest |element| (see KV_H2_SCALE_OFF above).
+// grid (n_kv * 8, n_layers), block KVF_THREADS; layer l reads partial + l * partial_layer_stride floats and writes
+// kvimg + l * image_layer_stride bytes.
+template <bool H2>
 __global__ __launch_bounds__(KVF_THREADS) void kv_finalize_image_kernel(const float* __restrict__ partial,
-                                                                   const int32_t* __restrict__ cloud_row0,
-                                                                   const int32_t* __restrict__ cloud_len, int64_t row_base,
-                                                                   int cloud_begin, char* __restrict__ kvimg,
-                                                                   int64_t partial_layer_stride, int64_t image_layer_stride) {
+                                                                      const int32_t* __restrict__ cloud_row0,
+                                                                      const int32_t* __restrict__ cloud_len, int64_t row_base,
+                                                                      int cloud_begin, char* __restrict__ kvimg,
+                                                                      int64_t partial_layer_stride, int64_t image_layer_stride) {
     constexpr int KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;
     static_assert(KV_ELEMS % 4 == 0 && KV_ELEMS / 4 <= KVF_THREADS, "");
+    __shared__ float wmax[KVF_THREADS / 64];
     // ONE pass, four consecutive elements per thread (264 of the 320 threads): with 1024 threads and one element each, the 32
     // Ksum elements cost a second trip through the whole reduction for half a wave -- the launch is latency, not bandwidth.
     const int i4 = threadIdx.x;
-    if (i4 >= KV_ELEMS / 4) return;
+    const bool active = i4 < KV_ELEMS / 4;
     const int kvi = blockIdx.x / SCREAM_NHEAD, h = blockIdx.x % SCREAM_NHEAD;
     const int cloud = cloud_begin + kvi;
     partial += (int64_t)blockIdx.y * partial_layer_stride;
     kvimg += (int64_t)blockIdx.y * image_layer_stride;
     const int t0 = (int)((cloud_row0[cloud] - row_base) / SCREAM_ROW_TILE);
     const int nt = (cloud_len[cloud] + SCREAM_ROW_TILE - 1) / SCREAM_ROW_TILE;
-    const float* p = partial + ((int64_t)t0 * SCREAM_NHEAD + h) * KV_ELEMS + 4 * i4;
+    const float* p = partial + ((int64_t)t0 * SCREAM_NHEAD + h) * KV_ELEMS + 4 * (active ? i4 : 0);
     char* img = kvimg + (size_t)cloud * KV_IMAGE_BYTES;
     const float S = (float)cloud_len[cloud];
     f32x4 s8[16];  // sixteen chains in a fixed combination order: deterministic (same order as kv_finalize_tiles_kernel)
 #pragma unroll
     for (int u = 0; u < 16; ++u) s8[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < nt; c += 16) {
+    if (active) {
+        for (int c = 0; c < nt; c += 16) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-            if (c + u < nt) s8[u] += *reinterpret_cast<const f32x4*>(p + (int64_t)(c + u) * SCREAM_NHEAD * KV_ELEMS);
+            for (int u = 0; u < 16; ++u)
+                if (c + u < nt) s8[u] += *reinterpret_cast<const f32x4*>(p + (int64_t)(c + u) * SCREAM_NHEAD * KV_ELEMS);
+        }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) s8[u] += s8[u + 8];
     const f32x4 s4 = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    const bool is_kv = 4 * i4 < 32 * 32;  // (the four elements of a thread are all K^T V or all Ksum: 1024 % 4 == 0)
+    f32x4 x4;                             // values / v_length (models/transformer.py:38-39), applied to the sum
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x4[e] = s4[e] / S;
+    float scale = 1.f;
+    if (H2) {
+        // the head's largest |KV / S| -> e_h = the largest exponent with max 2^e_h <= 2^15, clamped to [-30, 40] (an all-zero head: 40)
+        float m = (active && is_kv) ? fmaxf(fmaxf(fabsf(x4[0]), fabsf(x4[1])), fmaxf(fabsf(x4[2]), fabsf(x4[3]))) : 0.f;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = wmax[0];
+#pragma unroll
+        for (int w = 1; w < KVF_THREADS / 64; ++w) m = fmaxf(m, wmax[w]);
+        const uint32_t mb = __float_as_uint(m);
+        int eh = 15 - ((int)(mb >> 23) - 127) - ((mb & 0x7fffffu) ? 1 : 0);  // m = 1.f x 2^E: f == 0 -> 15 - E, else 14 - E
+        if (!(m >= 1.17549435e-38f) || eh > 40) eh = 40;                     // zero / subnormal / NaN maxima: nothing to protect
+        if (eh < -30) eh = -30;                                               // (|KV / S| > 2^45: outside anything the bounds allow)
+        scale = __uint_as_float((uint32_t)(eh + 127) << 23);
+        if (threadIdx.x < 8) reinterpret_cast<float*>(img + KV_H2_SCALE_OFF)[h * 8 + threadIdx.x] = __uint_as_float((uint32_t)(127 - eh) << 23);
+    }
+    if (!active) return;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int i = 4 * i4 + e;
-        const float s = s4[e];
-        if (i < 32 * 32) {
+        if (is_kv) {
             const int d = i >> 5, v = i & 31;             // partial layout [d][v]
-            const float x = s / S;                         // values / v_length (models/transformer.py:38-39), applied to the sum
+            const float x = x4[e];
             const int s2 = d >> 4, hf = (d >> 2) & 1, j = 4 * ((d >> 3) & 1) + (d & 3);  // d = chunk_k(s2, hf, j)
-            const __bf16 a = (__bf16)x;
-            const float r1 = x - (float)a;
-            const __bf16 b = (__bf16)r1;
-            const __bf16 cc = (__bf16)(r1 - (float)b);
-            __bf16* base = reinterpret_cast<__bf16*>(img) + ((size_t)(h * 3) * 2 + s2) * 512 + (v + 32 * hf) * 8 + j;
-            base[0] = a;
-            base[2 * 512] = b;
-            base[4 * 512] = cc;
+            if (H2) {
+                const _Float16 a = (_Float16)(x * scale);
+                const _Float16 b = (_Float16)__builtin_fmaf(x, scale, -(float)a);
+                _Float16* base = reinterpret_cast<_Float16*>(img) + ((size_t)(h * 2) * 2 + s2) * 512 + (v + 32 * hf) * 8 + j;
+                base[0] = a;
+                base[2 * 512] = b;
+            } else {
+                const __bf16 a = (__bf16)x;
+                const float r1 = x - (float)a;
+                const __bf16 b = (__bf16)r1;
+                const __bf16 cc = (__bf16)(r1 - (float)b);
+                __bf16* base = reinterpret_cast<__bf16*>(img) + ((size_t)(h * 3) * 2 + s2) * 512 + (v + 32 * hf) * 8 + j;
+                base[0] = a;
+                base[2 * 512] = b;
+                base[4 * 512] = cc;
+            }
         } else {
-            reinterpret_cast<float*>(img + KV_PLANES_BYTES)[h * 32 + (i - 32 * 32)] = s;
+            reinterpret_cast<float*>(img + KV_PLANES_BYTES)[h * 32 + (i - 32 * 32)] = s4[e];
         }
     }
 }
@@ -930,7 +995,10 @@ bool tail_scales(const scream_tail_exps_t* ex, TailScales* sc) {
         if (e < -40 || e > 40) return false;
     const int e1 = ex->e_wm + ex->e_att, e2 = ex->e_w2 + ex->e_h, eh = ex->e_h - ex->e_w1 - ex->e_m1;
     if (e1 < -44 || e1 > 44 || e2 < -44 || e2 > 44 || eh < -100 || eh > 100) return false;  // c^2 and c^2 * var stay finite in fp32
+    if (ex->e_q < -40 || ex->e_q > 40) return false;
     sc->s_att = exp2i(ex->e_att);
+    sc->s_q = exp2i(ex->e_q);
+    sc->s_attq = exp2i(ex->e_att - ex->e_q);
     sc->c1 = exp2i(e1);
     sc->eps1 = 1e-5f * exp2i(2 * e1);
     sc->s_m1 = exp2i(ex->e_m1);
@@ -974,16 +1042,21 @@ extern "C" int scream_pack_tail(const float* Wm, const float* W1, const float* W
 }
 
 extern "C" int scream_kv_finalize_image(const float* kv_partial, const int32_t* cloud_row0, const int32_t* cloud_len,
-                                     int64_t row_base, int32_t cloud_begin, int32_t n_kv, void* kv_image, int32_t n_layers,
-                                     int64_t partial_layer_stride, int64_t image_layer_stride, void* stream) {
-    SCREAM_REQUIRE(kv_partial && cloud_row0 && cloud_len && kv_image, SCREAM_EINVAL);
+                                        int64_t row_base, int32_t cloud_begin, int32_t n_kv, void* kv_image, int32_t n_layers,
+                                        int64_t partial_layer_stride, int64_t image_layer_stride, int32_t split, void* stream) {
+    SCREAM_REQUIRE(kv_partial && cloud_row0 && cloud_len && kv_image && split_ok(split), SCREAM_EINVAL);
     SCREAM_REQUIRE(n_kv >= 0 && cloud_begin >= 0 && row_base >= 0 && n_layers >= 1 && n_layers <= 65535, SCREAM_EINVAL);
     SCREAM_REQUIRE(n_layers == 1 || (partial_layer_stride > 0 && image_layer_stride > 0 && image_layer_stride % 16 == 0), SCREAM_EINVAL);
     SCREAM_REQUIRE(((reinterpret_cast<uintptr_t>(kv_image) | reinterpret_cast<uintptr_t>(kv_partial)) & 15) == 0 && partial_layer_stride % 4 == 0,
                    SCREAM_EINVAL);
     if (n_kv == 0) return 0;
-    kv_finalize_image_kernel<<<dim3(n_kv * SCREAM_NHEAD, n_layers), dim3(KVF_THREADS), 0, as_stream(stream)>>>(
-        kv_partial, cloud_row0, cloud_len, row_base, cloud_begin, reinterpret_cast<char*>(kv_image), partial_layer_stride, image_layer_stride);
+    const dim3 grid(n_kv * SCREAM_NHEAD, n_layers), block(KVF_THREADS);
+    if (split != SCREAM_SPLIT_BF3 && T_APPLY_H2)
+        kv_finalize_image_kernel<true><<<grid, block, 0, as_stream(stream)>>>(kv_partial, cloud_row0, cloud_len, row_base, cloud_begin,
+                                                                              reinterpret_cast<char*>(kv_image), partial_layer_stride, image_layer_stride);
+    else
+        kv_finalize_image_kernel<false><<<grid, block, 0, as_stream(stream)>>>(kv_partial, cloud_row0, cloud_len, row_base, cloud_begin,
+                                                                               reinterpret_cast<char*>(kv_image), partial_layer_stride, image_layer_stride);
     SCREAM_LAUNCH_CHECK();
     return 0;
 }
@@ -1012,7 +1085,7 @@ extern "C" int scream_layer_tail_f32(const float* Q, const void* kv_image, const
     SCREAM_REQUIRE(x != y, SCREAM_EINVAL);  // the residual of a row is read twice, long after its neighbours were written
     // q_next (the image then has its eight query stages): fp16 splits only; it may be Q itself, never x or y
     SCREAM_REQUIRE(!q_next || (split != SCREAM_SPLIT_BF3 && q_next != x && q_next != y), SCREAM_EINVAL);
-    TailScales sc{1.f, 1.f, 1e-5f, 1.f, 1.f, 1.f, 1e-5f, 1.f, 1.f};
+    TailScales sc{1.f, 1.f, 1.f, 1.f, 1e-5f, 1.f, 1.f, 1.f, 1e-5f, 1.f, 1.f};
     if (split != SCREAM_SPLIT_BF3) SCREAM_REQUIRE(tail_scales(exps, &sc), SCREAM_EINVAL);
     const int64_t tiles = M / SCREAM_ROW_TILE;
     if (tiles == 0) return 0;

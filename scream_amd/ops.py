@@ -142,7 +142,7 @@ def gemm_split(A: torch.Tensor, Wp: PackedW, epilogue: int = EPI_NONE, n_act: in
 
 def tail_exps(**kw) -> _lib.TailExpsT:
     e = _lib.TailExpsT()
-    for k in ("e_att", "e_wm", "e_m1", "e_w1", "e_h", "e_w2", "e_y", "e_wq"):
+    for k in ("e_att", "e_wm", "e_m1", "e_w1", "e_h", "e_w2", "e_y", "e_wq", "e_q"):
         setattr(e, k, int(kw.get(k, 0)))
     return e
 
@@ -172,9 +172,11 @@ def pack_tail(Wm: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, split: Optio
 
 
 def kv_finalize_image(partial: torch.Tensor, cloud_row0, cloud_len, row_base: int, cloud_begin: int, n_kv: int,
-                   n_clouds: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """K^T V partials of gemm_qkv -> the per-cloud operand image of layer_tail ([n_clouds, kv_image_bytes] uint8).
+                   n_clouds: int, out: Optional[torch.Tensor] = None, split: Optional[int] = None) -> torch.Tensor:
+    """K^T V partials of gemm_qkv -> the per-cloud operand image of layer_tail ([n_clouds, kv_image_bytes] uint8) for the tail of
+    the same `split` (default: default_split()): three bf16 planes, or two fp16 planes with a per-head exponent chosen on the device.
     partial [L, M/128, 8, 1056] (a batched key/value projection of L layers): returns [L, n_clouds, kv_image_bytes]."""
+    split = default_split() if split is None else split
     lib = _lib.load()
     L = partial.shape[0] if partial.dim() == 4 else 1
     img = lib.scream_kv_image_bytes()
@@ -182,7 +184,7 @@ def kv_finalize_image(partial: torch.Tensor, cloud_row0, cloud_len, row_base: in
         out = torch.zeros((L, n_clouds, img) if partial.dim() == 4 else (n_clouds, img), device=partial.device, dtype=torch.uint8)
     check(lib.scream_kv_finalize_image(_p(partial), _p(cloud_row0, torch.int32), _p(cloud_len, torch.int32), row_base,
                                     cloud_begin, n_kv, _p(out, torch.uint8), L, partial[0].numel() if L > 1 else 0,
-                                    n_clouds * img if L > 1 else 0, _stream()), "scream_kv_finalize_image")
+                                    n_clouds * img if L > 1 else 0, split, _stream()), "scream_kv_finalize_image")
     return out
 
 

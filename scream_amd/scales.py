@@ -71,9 +71,11 @@ def lin_bound(W: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias: Op
     return out.max().item()
 
 
-def tail_exps(Wm, W1, W2, g1, b1, v_bound: float) -> Dict[str, int]:
-    """Exponents of the layer tail (scream_tail_exps_t) from its weights and a bound on the value rows the attention mixes."""
+def tail_exps(Wm, W1, W2, g1, b1, v_bound: float, q_bound: float) -> Dict[str, int]:
+    """Exponents of the layer tail (scream_tail_exps_t) from its weights, a bound on the value rows the attention mixes and a bound
+    on the query projection q (Q' = elu(q) + 1 <= 1 + max(q, 0) is an fp16 x 2 operand of the attention apply since round 4)."""
     e_att = exp_for(v_bound)
+    e_q = exp_for(1.0 + q_bound)
     e_m1 = exp_for(ln_bound(g1, b1))
     e_h = exp_for(lin_bound(W1, g1, b1))
     e_wm, e_w1, e_w2 = w_exp(Wm), w_exp(W1), w_exp(W2)
@@ -86,13 +88,14 @@ def tail_exps(Wm, W1, W2, g1, b1, v_bound: float) -> Dict[str, int]:
         if e < -44:
             raise ScaleRangeError("the %s accumulators would be in units of 2^%d: outside the range the layer-tail kernel's LayerNorm "
                                   "arithmetic was checked for (use gemm_backend='x3')" % (name, e))
-    return {"e_att": e_att, "e_wm": e_wm, "e_m1": e_m1, "e_w1": e_w1, "e_h": e_h, "e_w2": e_w2}
+    return {"e_att": e_att, "e_wm": e_wm, "e_m1": e_m1, "e_w1": e_w1, "e_h": e_h, "e_w2": e_w2, "e_q": e_q}
 
 
 def layer_exps(m, in_q, in_kv) -> Dict[str, int]:
     """Exponents of one MHAttention block.  m: parameter holder (q_proj, k_proj, v_proj, merge, mlp, norm1, norm2);
     in_q / in_kv: (gamma, beta) of the LayerNorm that produced the query-side / key-value-side input."""
-    ex = tail_exps(m.merge.weight, m.mlp[0].weight, m.mlp[2].weight, m.norm1.weight, m.norm1.bias, lin_bound(m.v_proj.weight, *in_kv))
+    ex = tail_exps(m.merge.weight, m.mlp[0].weight, m.mlp[2].weight, m.norm1.weight, m.norm1.bias, lin_bound(m.v_proj.weight, *in_kv),
+                   lin_bound(m.q_proj.weight, *in_q))
     ex.update(e_xq=exp_for(ln_bound(*in_q)), e_xkv=exp_for(ln_bound(*in_kv)),
               # the projection's K^T V epilogue: K' = elu(k) + 1 <= 1 + max(k, 0), V = v
               e_k=exp_for(1.0 + lin_bound(m.k_proj.weight, *in_kv)), e_v=exp_for(lin_bound(m.v_proj.weight, *in_kv)))

@@ -43,11 +43,12 @@ def _gemm(kind, A, W, *a, **k):
     return ops.gemm_f32(A, W, *a, **k) if kind == "f32" else ops.gemm_split(A, ops.pack_w(W, SPLITS[kind]), *a, **k)
 
 
-def tail_exps_for(sd, pre, v_absmax):
-    """scream_tail_exps_t of block `pre` for inputs whose value rows stay below v_absmax (tests feed raw data, not LayerNorm
-    outputs, into single blocks: the forward derives the same exponents from the weights alone, scream_amd/scales.py)."""
+def tail_exps_for(sd, pre, v_absmax, q_absmax):
+    """scream_tail_exps_t of block `pre` for inputs whose value rows stay below v_absmax and whose query projections stay below
+    q_absmax (tests feed raw data, not LayerNorm outputs, into single blocks: the forward derives the same exponents from the
+    weights alone, scream_amd/scales.py)."""
     return ops.tail_exps(**scales.tail_exps(sd[pre + "merge.weight"], sd[pre + "mlp.0.weight"], sd[pre + "mlp.2.weight"],
-                                            sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], v_absmax))
+                                            sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], v_absmax, q_absmax))
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
@@ -410,11 +411,11 @@ def test_batched_key_value_projection_of_several_layers_equals_one_launch_per_la
     xd = dev(x[base:].clamp(-8, 8))
     _, part_all = ops.gemm_qkv(xd, ops.pack_w(dev(torch.cat(Ws)), SPL, w_exp), 0, tiles, crow0, clen, base, a_exp=a_exp)
     assert part_all.shape == (L, rows // 128, 8, 1056)
-    img_all = ops.kv_finalize_image(part_all, crow0, clen, base, 0, 3, 3)
+    img_all = ops.kv_finalize_image(part_all, crow0, clen, base, 0, 3, 3, split=SPL)
     for l in range(L):
         _, part = ops.gemm_qkv(xd, ops.pack_w(dev(Ws[l]), SPL, w_exp), 0, tiles, crow0, clen, base, a_exp=a_exp)
         assert torch.equal(part, part_all[l])
-        assert torch.equal(ops.kv_finalize_image(part, crow0, clen, base, 0, 3, 3), img_all[l])
+        assert torch.equal(ops.kv_finalize_image(part, crow0, clen, base, 0, 3, 3, split=SPL), img_all[l])
 
 
 @pytest.mark.parametrize("backend", ["h2", "x3"])
@@ -838,7 +839,7 @@ def test_fused_layer_tail_vs_oracle_block(cross, split):
     pk = lambda w: ops.pack_w(dev(w), SPL)
     v_absmax = float((x @ v.t()).abs().max()) * 1.01  # what bounds the attention output (scales.py derives it from the weights)
     img = ops.pack_tail(dev(sd[pre + "merge.weight"]), dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"]), SPL,
-                        tail_exps_for(sd, pre, v_absmax))
+                        tail_exps_for(sd, pre, v_absmax, float((x @ q.t()).abs().max()) * 1.01))
     g1, b1, g2, b2 = (dev(sd[pre + n]) for n in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"))
     xd = dev(x)
     xf = ops.act_layout(xd, True)  # the fused path passes activations FRAGMENT-major between its kernels
@@ -855,7 +856,7 @@ def test_fused_layer_tail_vs_oracle_block(cross, split):
         else:
             torch.testing.assert_close(ops.act_layout(Q, False), Qr, rtol=2e-6, atol=2e-6)
         assert torch.equal(part, part_r)
-        kvi = ops.kv_finalize_image(part, crow0, clen, 0, 0, 3, 3)
+        kvi = ops.kv_finalize_image(part, crow0, clen, 0, 0, 3, 3, split=SPL)
         y = ops.act_layout(ops.layer_tail(Q, kvi, dev(tiles), 0, clen, xf, img, g1, b1, g2, b2), False).cpu()
         for r0, xc in zip(row0, xs):
             want = O.mh_attention(xc[None], xc[None], xc[None], sd, pre)[0]
@@ -864,7 +865,7 @@ def test_fused_layer_tail_vs_oracle_block(cross, split):
         # queries: cloud 0 (rows 0..383); keys/values: cloud 2 (rows 640..) -- "source attends to target", kv_cloud_offset 2
         Q = ops.gemm_split(xf[:384], pk(q), ops.EPI_ELU1, n_act=256, layout=FR)
         _, part = ops.gemm_qkv(xf[640:], pk(Wkv), 0, dev(tiles), crow0, clen, 640, ops.LAYOUT_A_FRAG)
-        kvi = ops.kv_finalize_image(part, crow0, clen, 640, 2, 1, 3)
+        kvi = ops.kv_finalize_image(part, crow0, clen, 640, 2, 1, 3, split=SPL)
         y = ops.act_layout(ops.layer_tail(Q, kvi, dev(tiles[:3].contiguous()), 2, clen, xf[:384], img, g1, b1, g2, b2), False).cpu()
         want = O.mh_attention(xs[0][None], xs[2][None], xs[2][None], sd, pre)[0]
         torch.testing.assert_close(y[:300], want, rtol=2e-4, atol=5e-5)
@@ -898,9 +899,9 @@ def test_fused_layer_tail_many_tiles_equals_unfused_path(split):
     pk = lambda w: ops.pack_w(dev(w), SPL)
     Qf, part = ops.gemm_qkv(xf, pk(W), 256, tc, crow0, clen, 0, ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG)
     Q = ops.act_layout(Qf, False)
-    ex = tail_exps_for(sd, pre, float((x @ v.t()).abs().max()) * 1.01)
+    ex = tail_exps_for(sd, pre, float((x @ v.t()).abs().max()) * 1.01, float((x @ q.t()).abs().max()) * 1.01)
     img = ops.pack_tail(dev(sd[pre + "merge.weight"]), dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"]), SPL, ex)
-    kvi = ops.kv_finalize_image(part, crow0, clen, 0, 0, n_clouds, n_clouds)
+    kvi = ops.kv_finalize_image(part, crow0, clen, 0, 0, n_clouds, n_clouds, split=SPL)
     yf = ops.layer_tail(Qf, kvi, tc, 0, clen, xf, img, g1, b1, g2, b2)
     y = ops.act_layout(yf, False)
     kv = ops.kv_finalize(part, crow0, clen, 0, 0, n_clouds, n_clouds)
@@ -940,9 +941,9 @@ def test_layer_tail_with_the_next_layers_query_projection():
     xf = ops.act_layout(dev(x), True)
     SPL = ops.SPLIT_H2
     Qf, part = ops.gemm_qkv(xf, ops.pack_w(dev(W), SPL), 256, tc, crow0, clen, 0, ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG)
-    kvi = ops.kv_finalize_image(part, crow0, clen, 0, 0, n_clouds, n_clouds)
+    kvi = ops.kv_finalize_image(part, crow0, clen, 0, 0, n_clouds, n_clouds, split=SPL)
     exd = scales.tail_exps(sd[pre + "merge.weight"], sd[pre + "mlp.0.weight"], sd[pre + "mlp.2.weight"], sd[pre + "norm1.weight"],
-                           sd[pre + "norm1.bias"], float((x @ v.t()).abs().max()) * 1.01)
+                           sd[pre + "norm1.bias"], float((x @ v.t()).abs().max()) * 1.01, float((x @ q.t()).abs().max()) * 1.01)
     plain = ops.pack_tail(dev(sd[pre + "merge.weight"]), dev(sd[pre + "mlp.0.weight"]), dev(sd[pre + "mlp.2.weight"]), SPL, ops.tail_exps(**exd))
     y_plain = ops.layer_tail(Qf, kvi, tc, 0, clen, xf, plain, g1, b1, g2, b2)
     # y is a LayerNorm2 output: bounded by its gamma / beta, which is where the forward takes e_y from

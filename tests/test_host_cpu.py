@@ -358,7 +358,7 @@ def test_fp16_exponents_raise_outside_their_range_instead_of_clamping():
     # accumulator units below what the tail's LayerNorm arithmetic was checked for: tail_exps raises, scream_pack_tail is never reached
     g, b = torch.ones(256), torch.zeros(256)
     with pytest.raises(scales.ScaleRangeError, match="merge"):
-        scales.tail_exps(torch.full((256, 256), 2.0 ** 38), torch.ones(1024, 256), torch.ones(256, 1024), g, b, 2.0 ** 38)
+        scales.tail_exps(torch.full((256, 256), 2.0 ** 38), torch.ones(1024, 256), torch.ones(256, 1024), g, b, 2.0 ** 38, 1.0)
 
 
 def test_split_kernel_k_loop_has_no_register_spills(tmp_path):

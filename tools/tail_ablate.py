@@ -74,7 +74,7 @@ def run():
     clen[-1] = M - int(crow0[-1]) - 5
     A_EXP = scales.exp_for(XMAX)
     Wv = torch.cat([Wqkv[384:512], Wqkv[640:768]])
-    EX = ops.tail_exps(**scales.tail_exps(Wm, W1, W2, gam, bet, XMAX * float(Wv.abs().sum(dim=1).max())))
+    EX = ops.tail_exps(**scales.tail_exps(Wm, W1, W2, gam, bet, XMAX * float(Wv.abs().sum(dim=1).max()), XMAX * float(Wqkv[:256].abs().sum(dim=1).max())))
     pq, pm, p1, p2 = (ops.pack_w(w, split) for w in (Wqkv, Wm, W1, W2))
     xf = ops.act_layout(x, True)
     Qf, part = ops.gemm_qkv(xf, pq, 256, tile_cloud, crow0, clen, 0, 3, a_exp=A_EXP)
@@ -95,12 +95,12 @@ def run():
             ft = lib.scream_layer_tail_f32; ft.restype = ctypes.c_int
             ft.argtypes = [V, V, V, I32, V, V, V, V, V, V, V, V, V, I64, I32, ctypes.POINTER(_lib.TailExpsT), V]
             pt = lib.scream_pack_tail; pt.restype = ctypes.c_int; pt.argtypes = [V, V, V, V, I32, ctypes.POINTER(_lib.TailExpsT), V, V]
-            kf = lib.scream_kv_finalize_image; kf.restype = ctypes.c_int; kf.argtypes = [V, V, V, I64, I32, I32, V, I32, I64, I64, V]
+            kf = lib.scream_kv_finalize_image; kf.restype = ctypes.c_int; kf.argtypes = [V, V, V, I64, I32, I32, V, I32, I64, I64, I32, V]
             tb = lib.scream_tail_image_bytes; tb.restype = ctypes.c_int64; tb.argtypes = [I32, I32]
             timg = torch.empty(tb(split, 0), device=dev, dtype=torch.uint8)
             assert pt(Wm.data_ptr(), W1.data_ptr(), W2.data_ptr(), None, split, ctypes.byref(EX), timg.data_ptr(), st) == 0
             kvi = torch.zeros(n_clouds, lib.scream_kv_image_bytes(), device=dev, dtype=torch.uint8)
-            assert kf(part.data_ptr(), crow0.data_ptr(), clen.data_ptr(), 0, 0, n_clouds, kvi.data_ptr(), 1, 0, 0, st) == 0
+            assert kf(part.data_ptr(), crow0.data_ptr(), clen.data_ptr(), 0, 0, n_clouds, kvi.data_ptr(), 1, 0, 0, split, st) == 0
             calls.append(((tag + " " if tag else "") + "fused tail: " + label,
                           (lambda ft=ft, timg=timg, kvi=kvi: ft(Qf.data_ptr(), kvi.data_ptr(), tile_cloud.data_ptr(), 0, clen.data_ptr(), xf.data_ptr(),
                                                                 timg.data_ptr(), gam.data_ptr(), bet.data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(), None, M,

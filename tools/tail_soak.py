@@ -16,13 +16,13 @@ g1, b1, g2, b2 = (torch.randn(256, device=dev, generator=g) for _ in range(4))
 XMAX = 6.0  # the block inputs below are clamped to it, which bounds every operand without looking at the data
 A_EXP = scales.exp_for(XMAX)
 Wv = torch.cat([Wqkv[384:512], Wqkv[640:768]])  # the value rows of [q | k0-3 | v0-3 | k4-7 | v4-7]
-EX = ops.tail_exps(**scales.tail_exps(Wm, W1, W2, g1, b1, XMAX * float(Wv.abs().sum(dim=1).max())))
+EX = ops.tail_exps(**scales.tail_exps(Wm, W1, W2, g1, b1, XMAX * float(Wv.abs().sum(dim=1).max()), XMAX * float(Wqkv[:256].abs().sum(dim=1).max())))
 P = {sp: dict(q=ops.pack_w(Wqkv, sp), m=ops.pack_w(Wm, sp), w1=ops.pack_w(W1, sp), w2=ops.pack_w(W2, sp), img=ops.pack_tail(Wm, W1, W2, sp, EX))
      for sp in (ops.SPLIT_H2, ops.SPLIT_BF3)}
 # a third of the draws: the fp16 kernel with the NEXT layer's query projection behind norm2 (eight more ring stages, Q' written in place)
 Wqn = torch.randn(256, 256, device=dev, generator=g) / 16
 E_Y, E_WQ = scales.exp_for(scales.ln_bound(g2, b2)), scales.w_exp(Wqn)
-EXQ = ops.tail_exps(e_y=E_Y, e_wq=E_WQ, **scales.tail_exps(Wm, W1, W2, g1, b1, XMAX * float(Wv.abs().sum(dim=1).max())))
+EXQ = ops.tail_exps(e_y=E_Y, e_wq=E_WQ, **scales.tail_exps(Wm, W1, W2, g1, b1, XMAX * float(Wv.abs().sum(dim=1).max()), XMAX * float(Wqkv[:256].abs().sum(dim=1).max())))
 IMG_Q, PQN = ops.pack_tail(Wm, W1, W2, ops.SPLIT_H2, EXQ, Wq_next=Wqn), ops.pack_w(Wqn, ops.SPLIT_H2, E_WQ)
 FR = ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG
 torch.cuda.synchronize()
@@ -47,7 +47,7 @@ while time.time() - t0 < secs:
             p = P[(ops.SPLIT_H2, ops.SPLIT_BF3, ops.SPLIT_H2)[kind]]
             img = p["img"]
             Qf, part = ops.gemm_qkv(xf, p["q"], 256, tc, cr, cl, 0, FR, a_exp=A_EXP)
-            kvi = ops.kv_finalize_image(part, cr, cl, 0, 0, n_clouds, n_clouds)
+            kvi = ops.kv_finalize_image(part, cr, cl, 0, 0, n_clouds, n_clouds, split=(ops.SPLIT_H2, ops.SPLIT_BF3, ops.SPLIT_H2)[kind])
             if kind == 2:
                 qa, qb = Qf.clone(), Qf.clone()
                 y1 = ops.layer_tail(qa, kvi, tc, 0, cl, xf, IMG_Q, g1, b1, g2, b2, q_next=qa)
