@@ -441,6 +441,23 @@ def test_forward_batched_cross_key_values_equals_per_layer_launches(golden, back
             torch.testing.assert_close(outs[True], outs[False], rtol=2e-5, atol=2e-5)
 
 
+def test_forward_on_the_ring_projection_equals_the_gemm_projection(golden):
+    """The forward projects q/k/v on the ring kernel (net.ring_proj, default on the fp16 splits with the fused tail; csrc/proj_ring.hip)
+    or on the 8-wave GEMM (SCREAM_RING_PROJ=0 / net.ring_proj = False): the same products per element -- Q' is bit-identical -- with the
+    K^T V partial of a 128-row tile added up from two 64-row halves instead of four 32-row quarters: fp32-rounding-level agreement of
+    the outputs, and both reproduce the reference's."""
+    g = golden("e2e")
+    for seed, ns, nc, n, m, explicit in g["cases"]:
+        center = dev(g["center_%d" % seed]) if explicit else None
+        outs = {}
+        for ring in (True, False):
+            net = build_net(int(seed), int(ns), int(nc), "h2")
+            net.ring_proj = ring
+            outs[ring] = net(dev(g["src_%d" % seed]), dev(g["tgt_%d" % seed]), center, 1.0, False, False, None)[0]
+            np.testing.assert_allclose(outs[ring].cpu().numpy(), g["out_%d" % seed], rtol=2e-4, atol=5e-5, err_msg="case seed=%d" % seed)
+        torch.testing.assert_close(outs[True], outs[False], rtol=2e-5, atol=2e-5)
+
+
 # ----------------------------------------------------------------- A1-A6 whole forward pass
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_forward_vs_reference_golden(golden, backend):
