@@ -393,6 +393,28 @@ def test_ring_projection_vs_oracle_and_vs_the_eight_wave_gemm(split):
         torch.testing.assert_close(a[1:], b[1:], rtol=2e-5 if split == "h2" else 1e-3, atol=2e-5 if split == "h2" else 1e-3)
 
 
+def test_ring_projection_smallest_launches():
+    """One 128-row tile (a single 256-row unit range with two idle waves and fewer units than blocks), with and without queries, and
+    a six-layer key/value-only call on it: against the 8-wave GEMM (Q' bit for bit, K^T V per cloud to fp32 rounding)."""
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(128, 256, generator=g).clamp_(-6, 6)
+    tc, cr, cl = dev(torch.tensor([0], dtype=torch.int32)), dev(torch.tensor([0], dtype=torch.int32)), dev(torch.tensor([77], dtype=torch.int32))
+    xf = ops.act_layout(dev(x), True)
+    a_exp = scales.exp_for(6.0)
+    for N, n_q in ((768, 256), (512, 0), (3072, 0)):
+        W = torch.randn(N, 256, generator=g) / 16
+        w_exp = scales.w_exp(W)
+        rl = W.abs().sum(dim=1)[n_q:].view(-1, 2, 128)
+        kw = dict(a_exp=a_exp, k_exp=scales.exp_for(1.0 + 6.0 * float(rl[:, 0].max())), v_exp=scales.exp_for(6.0 * float(rl[:, 1].max())))
+        Q, part = ops.proj_qkv(xf, ops.pack_proj(dev(W), n_q, ops.SPLIT_H2, w_exp), tc, cr, cl, 0, **kw)
+        Qg, partg = ops.gemm_qkv(xf, ops.pack_w(dev(W), ops.SPLIT_H2, w_exp), n_q, tc, cr, cl, 0,
+                                 layout=ops.LAYOUT_A_FRAG | (ops.LAYOUT_C_FRAG if n_q else 0), **kw)
+        assert (Q is None and Qg is None) or torch.equal(Q[:77], Qg[:77]) or (Q[:77] - Qg[:77]).abs().max() < 2e-6
+        assert part.shape == partg.shape
+        for a, b in ([(part, partg)] if part.dim() == 3 else list(zip(part, partg))):
+            torch.testing.assert_close(ops.kv_finalize(a, cr, cl, 0, 0, 1, 1), ops.kv_finalize(b, cr, cl, 0, 0, 1, 1), rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("split", ["h2", "x3"])
 def test_batched_key_value_projection_of_several_layers_equals_one_launch_per_layer(split):
     """scream_gemm_qkv_split_f32 with N = 512 L, n_q == 0 (the cross stage's target side: the target features are frozen after
