@@ -113,6 +113,19 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float* __restrict_
         bi[u] = 0x7fffffff;
     }
 
+    // Round 4: the scan keeps only the running MINIMUM per chunk of NC targets (five arithmetic instructions + v_min per pair where
+    // compare + two selects made it eight); a chunk whose minimum beats the best so far (strict <, so the earliest chunk wins a
+    // tie) is remembered, and at the end of the tile the remembered chunk of each query is rescanned from LDS for the FIRST target
+    // that attains the minimum -- the same instruction sequence, hence the same bits, and the lowest index among equal distances,
+    // exactly what the scalar scan gave.  (A distance is never -0: it ends in an addition of |b|^2 >= +0.)
+    constexpr int NC = 32;
+    auto dist = [&](int u, const f32x4& b) __attribute__((always_inline)) {
+        float dot = __fmul_rn(ax[u], b[0]);
+        dot = __fmaf_rn(ay[u], b[1], dot);
+        dot = __fmaf_rn(az[u], b[2], dot);
+        // -2*dot is exact, so fma(-2, dot, |a|^2) rounds exactly like (-2*dot) + |a|^2
+        return __fadd_rn(__fmaf_rn(-2.0f, dot, sa[u]), b[3]);
+    };
     for (int jt = j_begin; jt < j_end; jt += RT) {
         const int cnt = min(RT, j_end - jt);
         __syncthreads();
@@ -120,20 +133,46 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const float* __restrict_
             *reinterpret_cast<f32x4*>(tile + i * 4) = *reinterpret_cast<const f32x4*>(rp + (int64_t)(jt + i) * 4);
         __syncthreads();
         if (!wave_has_queries) continue;  // (the last block of a cloud: 5 135 queries leave waves 1-3 of the sixth block without any)
-#pragma unroll 4
-        for (int j = 0; j < cnt; ++j) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(tile + j * 4);  // wave-uniform address: broadcast
+        int won[QPT];  // first target (tile-relative) of the chunk that lowered this query's best in this tile, or -1
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) won[u] = -1;
+        for (int c = 0; c < cnt; c += NC) {
+            const int ce = min(NC, cnt - c);
+            float cm[QPT];
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) cm[u] = __builtin_inff();
+            if (ce == NC) {
+#pragma unroll 8
+                for (int j = 0; j < NC; ++j) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(tile + (c + j) * 4);  // wave-uniform address: broadcast
+#pragma unroll
+                    for (int u = 0; u < QPT; ++u) cm[u] = fminf(cm[u], dist(u, b));
+                }
+            } else {
+                for (int j = 0; j < ce; ++j) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(tile + (c + j) * 4);
+#pragma unroll
+                    for (int u = 0; u < QPT; ++u) cm[u] = fminf(cm[u], dist(u, b));
+                }
+            }
 #pragma unroll
             for (int u = 0; u < QPT; ++u) {
-                float dot = __fmul_rn(ax[u], b[0]);
-                dot = __fmaf_rn(ay[u], b[1], dot);
-                dot = __fmaf_rn(az[u], b[2], dot);
-                // -2*dot is exact, so fma(-2, dot, |a|^2) rounds exactly like (-2*dot) + |a|^2
-                const float d = __fadd_rn(__fmaf_rn(-2.0f, dot, sa[u]), b[3]);
-                if (d < best[u]) {
-                    best[u] = d;
-                    bi[u] = jt + j;
+                if (cm[u] < best[u]) {
+                    best[u] = cm[u];
+                    won[u] = c;
                 }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+            if (won[u] >= 0) {  // (per lane: the rescan reads the lane's own chunk)
+                const int ce = min(NC, cnt - won[u]);
+                int first = ce;
+                for (int j = ce - 1; j >= 0; --j) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(tile + (won[u] + j) * 4);
+                    if (dist(u, b) == best[u]) first = j;
+                }
+                bi[u] = jt + won[u] + first;
             }
         }
     }
