@@ -11,6 +11,8 @@
 // a block stages 1024 targets (16 KiB) in LDS and every lane scans them with wave-uniform
 // (broadcast) ds_read_b128; each thread carries QPT query points, so one LDS read feeds QPT x 8 VALU
 // ops.  The kernel is VALU-bound (8 flop per pair over 12 bytes per POINT), not HBM-bound.
+#include <stdint.h>
+
 #include "common.h"
 #include "icp_grid.h"
 
@@ -295,14 +297,22 @@ extern "C" int scream_nn_search(const float* query, const float* ref, const int3
     if (max_q_len == 0) return 0;
     if (max_r_len > 0) {
         const int qblocks = (max_q_len + QB - 1) / QB;
-        // split the target range until the grid has >= ~4 blocks per CU; every split is a whole number of LDS tiles
-        int splits = (1024 + qblocks * n_pairs - 1) / (qblocks * n_pairs);
-        const int max_splits = (max_r_len + RT - 1) / RT;
-        if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
-        if (splits > 65535) splits = 65535;
+        // split the target range so that the launch is a whole number of rounds of equal blocks on the 256 CUs when it can be (5 k
+        // points: 6 query blocks x 4 splits x 32 pairs = 768 blocks = 3 per CU, where six splits of 1 024 left 4 full blocks on some
+        // CUs and 3 on others): the split count in [1, 64] that minimises rounds x targets per split; results do not depend on it
+        // (the 64-bit (distance, index) keys of the splits are merged with atomicMin)
+        const int max_splits = (max_r_len + 255) / 256 < 64 ? (max_r_len + 255) / 256 : 64;
+        int splits = 1;
+        int64_t best_cost = INT64_MAX;
+        for (int sp = 1; sp <= (max_splits > 0 ? max_splits : 1); ++sp) {
+            const int64_t blocks = (int64_t)qblocks * sp * n_pairs, per = (max_r_len + sp - 1) / sp;
+            const int64_t cost = ((blocks + 255) / 256) * (per + 64);  // (+ 64: a block's fixed cost in units of targets)
+            if (cost < best_cost) {
+                best_cost = cost;
+                splits = sp;
+            }
+        }
         int r_per_split = (max_r_len + splits - 1) / splits;
-        r_per_split = (r_per_split + RT - 1) / RT * RT;
         splits = (max_r_len + r_per_split - 1) / r_per_split;
         nn_search_kernel<<<dim3(qblocks, splits, n_pairs), dim3(256), 0, st>>>(query, ref_prep, q_row0, q_len, r_row0,
                                                                               r_len, s, r_per_split, keys);
