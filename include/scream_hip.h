@@ -173,6 +173,8 @@ int scream_proj_qkv_f32(const float* x, const void* proj_image, float* Q, int64_
 typedef struct {
     int32_t e_att, e_wm, e_m1, e_w1, e_h, e_w2;
     int32_t e_y, e_wq; /* only with a next-layer query projection in the image (below): of the block output y and of that Wq */
+    int32_t e_x;       /* q_first images only (scream_pack_tail): of the block INPUT x as the operand of this layer's own query projection (e_wq: of
+                        * that Wq) */
     int32_t e_q;       /* of Q' = elu(q) + 1 as an operand of the attention apply (fp16 x 2 since round 4): |Q'| 2^e_q <= 2^15, Q' <= 1 + the
                         * bound of the query projection (scream_amd/scales.py: 16 |w * gamma|_2 + |w . beta| over the rows of Wq) */
 } scream_tail_exps_t;
@@ -182,7 +184,12 @@ int64_t scream_kv_image_bytes(void);
  * block's output rows (a cross layer behind a self layer, models/transformer.py:130): eight more stages in the image, and
  * scream_layer_tail_f32 called with q_next != NULL ends every tile with Q'_next = elu(y . Wq_next^T) + 1 (fragment-major) --
  * the separate scream_gemm_split_f32(..., SCREAM_EPI_ELU1) launch of that layer is then not needed. */
-int scream_pack_tail(const float* Wm, const float* W1, const float* W2, const float* Wq_next, int32_t split,
+/* EXPERIMENTAL (round 4; off in scream_amd/model.py -- results are not repeatable bit for bit beside other kernels, root cause open:
+ * profiles/r04_qf_experiment.txt).  q_first != 0 (fp16 splits): Wq_next is THIS layer's q_proj.weight and its eight stages come FIRST in the image:
+ * scream_layer_tail_f32 called with Q == NULL then begins every tile with Q' = elu(x . Wq^T) + 1 of its own rows, kept in registers
+ * for the applies -- Q' is neither written by a projection launch nor read here (x is read anyway: the residual of both norms);
+ * the projection of such a layer computes key/value chunks only (n_q = 0).  exps->e_x / e_wq: of x and of Wq as operands. */
+int scream_pack_tail(const float* Wm, const float* W1, const float* W2, const float* Wq_next, int32_t q_first, int32_t split,
                      const scream_tail_exps_t* exps, void* tail_image, void* stream);
 /* n_layers > 1: the partials of a batched key/value projection (scream_gemm_qkv_split_f32 with N = 512 n_layers): layer l
  * reads kv_partial + l * partial_layer_stride floats ((M/128) * 8 * 1056 of that GEMM) and writes its n_kv cloud images at
@@ -259,6 +266,11 @@ typedef struct {
     /* fused-tail models on the fp16 splits only; may be NULL.  scream_pack_proj image of wqkv (exponent e_wqkv): the q/k/v
      * projection of a self layer then runs on scream_proj_qkv_f32 and ignores wqkv. */
     const void* proj;
+    /* the tail image was packed with q_first (this layer's own Wq in front): the forward then launches no query projection for this
+     * layer -- a self layer projects key/value chunks only (proj_kv: scream_pack_proj image of wkv with n_q = 0, or wkv on the GEMM),
+     * a cross layer nothing on the query side -- and calls scream_layer_tail_f32 with Q == NULL */
+    int32_t tail_q_first;
+    const void* proj_kv;
 } scream_layer_t;
 
 typedef struct {

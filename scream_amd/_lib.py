@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SCREAM_LIB=<path>: load that build instead (A/B runs of two builds on the same GPU box; never built automatically)
 LIB_PATH = os.environ.get("SCREAM_LIB") or os.path.join(_HERE, "libscream_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -25,13 +25,13 @@ SPLIT_H1, SPLIT_H2, SPLIT_BF3 = 1, 2, 3
 
 
 class TailExpsT(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("e_att", "e_wm", "e_m1", "e_w1", "e_h", "e_w2", "e_y", "e_wq", "e_q")]
+    _fields_ = [(n, C.c_int32) for n in ("e_att", "e_wm", "e_m1", "e_w1", "e_h", "e_w2", "e_y", "e_wq", "e_x", "e_q")]
 
 
 class LayerT(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("wqkv", "wq", "wkv", "wm", "w1", "w2", "g1", "b1", "g2", "b2", "tail")] +
                 [(n, C.c_int32) for n in ("e_xq", "e_xkv", "e_wqkv", "e_wq", "e_wkv", "e_wm_g", "e_w1_g", "e_w2_g", "e_k", "e_v")] +
-                [("tail_exps", TailExpsT), ("tail_next_q", C.c_int32), ("proj", C.c_void_p)])
+                [("tail_exps", TailExpsT), ("tail_next_q", C.c_int32), ("proj", C.c_void_p), ("tail_q_first", C.c_int32), ("proj_kv", C.c_void_p)])
 
 
 class ModelT(C.Structure):
@@ -67,7 +67,7 @@ SIGNATURES = {
     "scream_proj_qkv_f32": (C.c_int, [V, V, V, I64, I32, I32, V, V, V, I64, V, I32, I32, I32, I32, I32, V]),
     "scream_tail_image_bytes": (C.c_int64, [I32, I32]),
     "scream_kv_image_bytes": (C.c_int64, []),
-    "scream_pack_tail": (C.c_int, [V, V, V, V, I32, C.POINTER(TailExpsT), V, V]),
+    "scream_pack_tail": (C.c_int, [V, V, V, V, I32, I32, C.POINTER(TailExpsT), V, V]),
     "scream_kv_finalize_image": (C.c_int, [V, V, V, I64, I32, I32, V, I32, I64, I64, I32, V]),
     "scream_layer_tail_f32": (C.c_int, [V, V, V, I32, V, V, V, V, V, V, V, V, V, I64, I32, C.POINTER(TailExpsT), V]),
     "scream_act_layout": (C.c_int, [V, V, I64, I32, V]),

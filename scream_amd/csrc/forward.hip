@@ -142,16 +142,18 @@ int mha_self(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, con
     const float* xr = x + row0 * D;
     float* qr = w.q + row0 * D;
     float* kvp = w.kvp + row0 / SCREAM_ROW_TILE * SCREAM_NHEAD * KV_ELEMS;
-    TRY(gemm_qkv(c, xr, L.wqkv, L.proj, qr, rows, 3 * D, D, b, row0, kvp, L.e_xq, L.e_wqkv, L.e_k, L.e_v));
+    const bool qf = c.frag && L.tail_q_first;  // the layer tail projects its own queries: key/value chunks only here
+    if (qf) TRY(gemm_qkv(c, xr, L.wkv, L.proj_kv, nullptr, rows, 2 * D, 0, b, row0, kvp, L.e_xkv, L.e_wkv, L.e_k, L.e_v));
+    else TRY(gemm_qkv(c, xr, L.wqkv, L.proj, qr, rows, 3 * D, D, b, row0, kvp, L.e_xq, L.e_wqkv, L.e_k, L.e_v));
     if (c.frag) {  // apply + merge + norm1 + FFN + norm2 in one launch
         {
             Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
             TRY(scream_kv_finalize_image(kvp, b.cloud_row0, b.cloud_len, row0, cloud_begin, n_clouds, w.kvimg, 1, 0, 0, c.split, c.st));
         }
         // merge (256) + FFN up and down (2 x 1024) (+ the next layer's query projection, 256) output columns per row
-        Scope sc(c.tr, TR_TAIL_FUSED, rows, (next_q ? 10 : 9) * D, D, c.st);
-        return scream_layer_tail_f32(qr, w.kvimg, b.tile_cloud + row0 / SCREAM_ROW_TILE, 0, b.cloud_len, xr, L.tail, L.g1,
-                                     L.b1, L.g2, L.b2, y + row0 * D, next_q ? qr : nullptr, rows, c.split, &L.tail_exps, c.st);
+        Scope sc(c.tr, TR_TAIL_FUSED, rows, ((next_q || qf) ? 10 : 9) * D, D, c.st);
+        return scream_layer_tail_f32(qf ? nullptr : qr, w.kvimg, b.tile_cloud + row0 / SCREAM_ROW_TILE, 0, b.cloud_len, xr, L.tail, L.g1,
+                                     L.b1, L.g2, L.b2, y + row0 * D, (next_q && !qf) ? qr : nullptr, rows, c.split, &L.tail_exps, c.st);
     }
     {
         Scope sc(c.tr, TR_KV_REDUCE, rows, 0, 0, c.st);
@@ -188,13 +190,14 @@ int cross_kv_all(const Ctx& c, const scream_model_t& m, const scream_batch_t& b,
 int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, const Workspace& w, const float* x_src,
               const float* x_tgt, float* y, const char* kvimg_layer, bool q_ready = false) {
     const int64_t rs = b.rows_src, rt = b.rows_total - b.rows_src;
-    if (!q_ready)
+    const bool qf = c.frag && L.tail_q_first;  // the layer tail projects its own queries from x_src
+    if (!q_ready && !qf)
         TRY(gemm(c, x_src, D, L.wq, w.q, D, rs, D, D, SCREAM_EPI_ELU1, D, nullptr, nullptr, nullptr, nullptr, L.e_xq, L.e_wq,
                  c.frag ? (SCREAM_LAYOUT_A_FRAG | SCREAM_LAYOUT_C_FRAG) : 0));
     if (c.frag && kvimg_layer) {
-        Scope sc(c.tr, TR_TAIL_FUSED, rs, 9 * D, D, c.st);
+        Scope sc(c.tr, TR_TAIL_FUSED, rs, (qf ? 10 : 9) * D, D, c.st);
         // tile_cloud holds source cloud i for the source tiles; its target cloud's image is entry i of this layer's block
-        return scream_layer_tail_f32(w.q, kvimg_layer, b.tile_cloud, 0, b.cloud_len + b.n_pairs, x_src, L.tail, L.g1, L.b1, L.g2,
+        return scream_layer_tail_f32(qf ? nullptr : w.q, kvimg_layer, b.tile_cloud, 0, b.cloud_len + b.n_pairs, x_src, L.tail, L.g1, L.b1, L.g2,
                                      L.b2, y, nullptr, rs, c.split, &L.tail_exps, c.st);
     }
     TRY(gemm_qkv(c, x_tgt, L.wkv, nullptr, nullptr, rt, 2 * D, 0, b, rs, w.kvp, L.e_xkv, L.e_wkv, L.e_k, L.e_v));
@@ -203,8 +206,8 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
             Scope sc(c.tr, TR_KV_REDUCE, rt, 0, 0, c.st);
             TRY(scream_kv_finalize_image(w.kvp, b.cloud_row0, b.cloud_len, rs, b.n_pairs, b.n_pairs, w.kvimg, 1, 0, 0, c.split, c.st));
         }
-        Scope sc(c.tr, TR_TAIL_FUSED, rs, 9 * D, D, c.st);
-        return scream_layer_tail_f32(w.q, w.kvimg, b.tile_cloud, b.n_pairs, b.cloud_len, x_src, L.tail, L.g1, L.b1, L.g2, L.b2,
+        Scope sc(c.tr, TR_TAIL_FUSED, rs, (qf ? 10 : 9) * D, D, c.st);
+        return scream_layer_tail_f32(qf ? nullptr : w.q, w.kvimg, b.tile_cloud, b.n_pairs, b.cloud_len, x_src, L.tail, L.g1, L.b1, L.g2, L.b2,
                                      y, nullptr, rs, c.split, &L.tail_exps, c.st);
     }
     {
@@ -220,8 +223,8 @@ int mha_cross(const Ctx& c, const scream_layer_t& L, const scream_batch_t& b, co
 
 }  // namespace
 
-extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi17"; }
-extern "C" int scream_abi_version(void) { return 17; }
+extern "C" const char* scream_version(void) { return "scream_hip gfx950 abi18"; }
+extern "C" int scream_abi_version(void) { return 18; }
 
 extern "C" void* scream_trace_create(int32_t capacity) {
     if (capacity <= 0) return nullptr;

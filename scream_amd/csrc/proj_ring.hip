@@ -43,7 +43,8 @@
 #define P_LB 2  // x segments per load batch at a tile boundary (two batches in flight)
 #endif
 #ifndef P_ABLATE
-#define P_ABLATE 0  // tuning aid (SCREAM_HIPCC_EXTRA builds): 1 no rides (epilogues dropped), 2 no MFMA, 8 no W DMA after the first two stages (-DT_ABLATE=4: no LDS fragment reads)
+#define P_ABLATE 0  // tuning aid (SCREAM_HIPCC_EXTRA builds): 1 no rides (epilogues dropped), 2 no MFMA, 8 no W DMA after the first two stages (-DT_ABLATE=4: no LDS fragment reads);
+                    // inside the rides: 32 elu + 1 without its exponential, 64 no Q' stores, 128 no K'^T V products, 256 no operand splits of K' and V, 512 no slab / partial traffic
 #endif
 
 namespace {
@@ -244,11 +245,11 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) t[rg][2 * g + e] = elu1s(t[rg][2 * g + e], pa.ec);
+                for (int e = 0; e < 2; ++e) t[rg][2 * g + e] = (P_ABLATE & 32) ? fmaxf(__builtin_fmaf(t[rg][2 * g + e], pa.ec.c, 1.0f), 0.25f) : elu1s(t[rg][2 * g + e], pa.ec);
         }
         if (g == 8) {
             __builtin_amdgcn_sched_barrier(0);
-            if (q_pend_ok) {
+            if (q_pend_ok && (!(P_ABLATE & 64) || t[0][0] == 123.456f)) {
 #pragma unroll
                 for (int rg = 0; rg < 2; ++rg)
 #pragma unroll
@@ -267,10 +268,10 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
         if (g == 0) ks = 0.f;
 #pragma unroll
         for (int rg = 0; rg < 2; ++rg) {
-            float a = elu1s(t[rg][g], pa.ec);
+            float a = (P_ABLATE & 32) ? fmaxf(__builtin_fmaf(t[rg][g], pa.ec.c, 1.0f), 0.25f) : elu1s(t[rg][g], pa.ec);
             if (decltype(mask)::value && (g & 3) + 8 * (g >> 2) + 32 * rg >= valid) a = 0.f;  // row mfma32_row(g, half) + 32 rg of the wave's 64 (valid carries the half)
             ks += a;
-            SplitH2::split1s(a, pa.kv_sk, g & 7, kp[rg][g >> 3]);
+            if (P_ABLATE & 256) kp[rg][g >> 3][0][g & 7] = (_Float16)a; else SplitH2::split1s(a, pa.kv_sk, g & 7, kp[rg][g >> 3]);
         }
         if (g == 15) ks += __shfl_xor(ks, 32);
     };
@@ -284,18 +285,23 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int i = 8 * s2 + 2 * (g & 3) + e;
-                    SplitH2::split1s(t[rg][i], pa.kv_cv, i & 7, vp[rg]);
+                    if (P_ABLATE & 256) vp[rg][0][i & 7] = (_Float16)t[rg][i]; else SplitH2::split1s(t[rg][i], pa.kv_cv, i & 7, vp[rg]);
                 }
             if ((g & 3) == 3) {
                 f32x16 z;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) z[e] = 0.f;
-                SplitH2::products(kv, kp[0][s2], vp[0], s2 == 0 ? z : kv);
-                SplitH2::products(kv, kp[1][s2], vp[1], kv);
+                if (P_ABLATE & 128) {
+                    kv = s2 == 0 ? z : kv;
+                    kv[0] += (float)kp[0][s2][0][0] + (float)vp[0][0][0] + (float)kp[1][s2][1][1] + (float)vp[1][1][1];
+                } else {
+                    SplitH2::products(kv, kp[0][s2], vp[0], s2 == 0 ? z : kv);
+                    SplitH2::products(kv, kp[1][s2], vp[1], kv);
+                }
             }
         }
         if (g == 9) kv *= pa.kv_inv;  // exact: a power of two (1 / v_length is applied once, in scream_kv_finalize_image)
-        if (g >= 10 && g < 14) {
+        if (g >= 10 && g < 14 && (!(P_ABLATE & 512) || kv[0] == 123.456f)) {
             float* sw = slabs + wave * P_KV_ELEMS;
 #pragma unroll
             for (int e = 4 * (g - 10); e < 4 * (g - 9); ++e) sw[mfma32_row(e, half) * 32 + r] = kv[e];  // [d][v]
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
     auto ride_kvstore = [&](int g) __attribute__((always_inline)) {
         if (g > 8) return;
         const int i = (wave & 1) * 64 + lane + 128 * g;
-        if (i < P_KV_ELEMS && part_pend_ok) {
+        if (i < P_KV_ELEMS && part_pend_ok && !(P_ABLATE & 512)) {
             const float* s2 = slabs + (wave & ~1) * P_KV_ELEMS + i;
             part_pend[i] = s2[0] + s2[P_KV_ELEMS];
         }

@@ -64,6 +64,12 @@
 #ifndef T_RIDE0
 #define T_RIDE0 3  // SplitH2: first MFMA group of a down stage that carries a relu / split pair of the ride (eight groups from there); 0 / 3 / 6: 1.044 / 1.040 / 1.041 ms per 333 k-row launch (profiles/r04_tail_ride0_ab.txt)
 #endif
+#ifndef T_QF_DUMP
+#define T_QF_DUMP 0
+#endif
+#ifndef T_QF_DBG
+#define T_QF_DBG 0  // debugging aid for the QF kernel: 1 full drain + barrier at the first query stage, 2 the applies of heads 0 / 1 in the open, 4 no deferral across query stages
+#endif
 #ifndef T_DEFER_H2
 #define T_DEFER_H2 2  // SplitH2: MFMA groups of a stage deferred across the barrier into the next stage (1 or 2)
 #endif
@@ -132,6 +138,8 @@ struct TailScales {
     float eps2;   // 1e-5 c2^2
     float s_y;    // NQ: 2^e_y, the block OUTPUT as the operand of the next layer's query projection
     float cq;     // NQ: 2^-(e_y + e_wq): accumulator of that projection -> q
+    float s_x;    // QF: 2^e_x, the block INPUT as the operand of this layer's query projection
+    float cqf;    // QF: 2^-(e_x + e_wq)
 };
 
 // merge stage h (h >= 1): which quarter of the x-segment add rides in group g (-1: none) -- the last four groups of
@@ -150,8 +158,12 @@ __device__ __forceinline__ constexpr int xadd_slot(int h, int g, int nd) {
 // block's output rows, models/transformer.py:130), and the kernel ends every tile with  Q'_next = elu(y . Wq^T) + 1  -- y is in
 // registers in operand layout the moment norm2 is done, so the separate projection launch (x re-read, re-split, one more launch
 // per layer with its partial last round) disappears.  q_next may alias Q: a tile reads its own rows of Q long before it writes them.
-template <class SP, bool NQ>
-__global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q,      // fragment-major [M, 256]
+// QF (round 4, fp16 splits): the image carries eight more stages IN FRONT -- Wq of THIS layer -- and every tile begins with
+// Q' = elu(x . Wq^T) + 1 of its own rows, head by head, kept in registers for the applies: Q' is neither written by the projection
+// (1 KB per row: 11 % of a projection launch by the ablation, profiles/r04_ring_proj_ride_ablation.txt) nor read back here, and the
+// projection kernel shrinks to the key/value chunks.  x is in the tile's hands anyway (the residual of both norms).  Q is unused.
+template <class SP, bool NQ, bool QF>
+__global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q,      // fragment-major [M, 256] (QF: unused)
                                                      const char* __restrict__ kvimg,   // [n_clouds][KV_IMAGE_BYTES]
                                                      const int32_t* __restrict__ tile_cloud, int kv_cloud_offset,
                                                      const int32_t* __restrict__ cloud_len,
@@ -163,7 +175,8 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
                                                      float* q_next,                    // NQ: fragment-major [M, 256] (may alias Q)
                                                      int n_tiles, TailScales sc) {
     static_assert(!NQ || SP::SCALED, "the next-layer query projection is built for the fp16 splits");
-    constexpr int N_STAGES = TAIL_STAGES + (NQ ? NEXT_Q_STAGES : 0);
+    static_assert(!QF || (SP::SCALED && !NQ), "the in-kernel query projection is built for the fp16 splits and replaces the next-layer one");
+    constexpr int N_STAGES = TAIL_STAGES + ((NQ || QF) ? NEXT_Q_STAGES : 0);
     typedef typename SP::vec V;
     constexpr int NP = SP::NP;
     constexpr int STAGE = stage_bytes<SP>();
@@ -327,14 +340,28 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         if (g >= 4 && g < 12) apply_split_pair(g - 4, ap, S);
     };
 
+    // ---- QF: this layer's query projection in front of the merge stages --------------------------------------------------------
+    V xp[QF ? 16 : 1][NP];        // operand planes of the wave's x rows (B operand of the eight query stages)
+    f32x4 qall[QF ? 8 : 1][4];    // Q' of every head, fp32, in the piece layout the applies consume (what req_q loads otherwise)
+    f32x16 hqf[2];                // query chunk accumulators, alternating
+    auto elu_q = [&](int k, const f32x16& h, f32x4 (&dst)[4]) {  // elements 2k, 2k + 1 of a finished chunk
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = 2 * k + e;
+            dst[i >> 2][i & 3] = elu1(h[i] * sc.cqf);
+        }
+    };
+
     int tile = blockIdx.x;
     int64_t grp = ((int64_t)tile * 128 + wave * 32) * SCREAM_D_MODEL;  // first float of this wave's 32-row group
     const char* kvc = nullptr;
     float S = 1.f;
-    if (tile < n_tiles) {  // the block's first tile: heads 0 and 1 are applied in the open (once per block)
+    if (tile < n_tiles) {
         const int cl = tile_cloud[tile] + kv_cloud_offset;
         kvc = kvimg + (size_t)cl * KV_IMAGE_BYTES;
         S = (float)cloud_len[cl];
+    }
+    if (!QF && tile < n_tiles) {  // the block's first tile: heads 0 and 1 are applied in the open (once per block)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             req_q(qA, grp, h);
@@ -391,7 +418,10 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
             // still be in flight, and nothing of this stage depends on them)
             // (NQ: the previous tile ended in ring stages whose last chunk's STORES are the youngest operations in the queue -- a counted
             // wait is only sound among loads, so this one barrier per tile drains)
-            if (h == 0) { if (NQ) ring_barrier<0>(); else lds_only_barrier(); } else ring_barrier<PIECES>();
+            // (QF: the query stages sit in front, so merge stage 0 is an ordinary ring stage)
+            if (h == 0 && !QF) { if (NQ) ring_barrier<0>(); else lds_only_barrier(); }
+            else if (QF && (T_QF_DBG & 32) && h <= 1) ring_barrier<0>();
+            else ring_barrier<PIECES>();
             TMARK(h);  // T_STAMPS builds: marks 0-7 = the tops of the merge stages
             __builtin_amdgcn_sched_barrier(0);
             f32x4 (&x_prev)[4] = (h & 1) ? xs : xs2;   // segment h - 1 (landed: requested by stage h - 1)
@@ -405,7 +435,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
             }
             __builtin_amdgcn_sched_barrier(0);
             req_x(x_req, grp, h);
-            if (h + 2 < 8) req_q(q_req, grp, h + 2);  // consumed by stage h + 1
+            if (!QF && h + 2 < 8) req_q(q_req, grp, h + 2);  // consumed by stage h + 1 (QF: Q' of every head is in registers already)
             if (h == 0) req_head(op, kvc, 2);
             __builtin_amdgcn_sched_barrier(0);
             const char* wb = smem + (q % T_SLOTS) * STAGE + lane * 16;
@@ -430,6 +460,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
                 if (g >= 4 && g - 4 < PIECES) dma_piece(q + 2, g - 4);
                 if (PIECES == 12 && g == 14) dma_piece(q + 2, 11);  // (group 15 is deferred: the twelfth piece goes out with the eleventh)
                 if (RIDE && !(T_ABLATE & 512)) apply_ride(q_cons, g, ap_next, S, tile);
+                if (QF && h == 0 && g < 8) elu_q(g, hqf[1], qall[QF ? 7 : 0]);  // the last query chunk (its deferred groups were flushed above)
                 // the norm1 residual: segment h - 1 joins accumulator tile h - 1 in quarters, in late groups that do not
                 // accumulate into that tile (its MFMAs are groups 2h - 2 and 2h - 1)
                 if (h > 0) {
@@ -452,6 +483,97 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         auto flush_mergeA = [&]() { flush_acc7(apA, false); };  // deferred groups of a merge stage of an even head
         auto flush_mergeB = [&]() { flush_acc7(apB, false); };
         auto flush_mergeA0 = [&]() { flush_acc7(apA, true); };  // ... of stage 0, which starts the accumulator tiles
+        if constexpr (QF) {
+            // ---- Q' = elu(x . Wq^T) + 1 of this tile, head j in ring stage j (an FFN-up stage with x's planes as the operand); the elu of
+            // chunk j - 1 rides in stage j, the applies of heads 0 and 1 ride in stages 6 and 7 (their KV operands are requested one stage
+            // ahead, before the stage's weight pieces, as in the merge stages), everything else of the merge phase is unchanged.
+            {
+                f32x4 raw[8][4];  // the wave's 32 rows: piece a of segment blk = one contiguous 1 KiB per wave instruction
+                const float* xg = xres + grp + lane * 4;
+#pragma unroll
+                for (int blk = 0; blk < 8; ++blk)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) raw[blk][a] = ld4(xg + (blk * 4 + a) * 256);
+                VM_WAIT(0);  // (also: this wave's pieces of the tile's first two ring stages have landed -- stage 0 starts with an LDS-only barrier)
+#pragma unroll
+                for (int blk = 0; blk < 8; ++blk)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) split8s<SP>(raw[blk][2 * s2], raw[blk][2 * s2 + 1], sc.s_x, xp[QF ? 2 * blk + s2 : 0]);
+            }
+            auto stage_qf = [&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                constexpr int RIDE = j >= 6 ? j - 6 : -1;  // the head whose apply rides here
+                constexpr bool RIDE6 = !(T_QF_DBG & (2 | 64)), RIDE7 = !(T_QF_DBG & (2 | 128));
+                constexpr bool RIDE_ON = j == 6 ? RIDE6 : RIDE7;
+                if (j == 0) { if (T_QF_DBG & 1) ring_barrier<0>(); else lds_only_barrier(); }
+                else if ((T_QF_DBG & 8) && j >= 6) ring_barrier<0>();
+                else if ((T_QF_DBG & 16) && j >= 1 && j <= 5) ring_barrier<0>();
+                else ring_barrier<PIECES>();
+                __builtin_amdgcn_sched_barrier(0);
+                if (RIDE >= 0 && RIDE_ON) pin_head(op);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 5 && RIDE6) req_head(op, kvc, 0);
+                if (j == 6 && !RIDE6 && RIDE7) req_head(op, kvc, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const char* wb = smem + (q % T_SLOTS) * STAGE + lane * 16;
+                V wf[T_PF][NP];
+#pragma unroll
+                for (int g0 = 0; g0 < T_PF - 1; ++g0)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) wf[g0][p] = ld_frag<V>(wb + (p * 16 + g0) * 1024);
+                if (j > 0) {
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) mfma_group<SP, -1>(hqf[(j + 1) & 1], wfd[i], xp[QF ? NG + i : 0]);
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g + T_PF - 1 < 16) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p)
+                            (g + T_PF - 1 >= NG ? wfd[g + T_PF - 1 - NG][p] : wf[(g + T_PF - 1) % T_PF][p]) = ld_frag<V>(wb + (p * 16 + g + T_PF - 1) * 1024);
+                    }
+                    if (g == 4 && RIDE == 0 && RIDE6 && RIDE7) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        req_head(op, kvc, 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (g >= 4 && g - 4 < PIECES) dma_piece(q + 2, g - 4);
+                    if (j > 0 && g < 8) elu_q(g, hqf[(j + 1) & 1], qall[QF && j > 0 ? j - 1 : 0]);
+                    if (RIDE >= 0 && RIDE_ON && !(T_ABLATE & 512)) apply_ride(qall[QF && RIDE >= 0 ? RIDE : 0], g, RIDE == 0 ? apA : apB, S, tile);
+                    mfma_group<SP, 8>(hqf[j & 1], wf[g % T_PF], xp[QF ? g : 0], g == 0);
+                }
+                ++q;
+            };
+            stage_qf(HEAD(0)); stage_qf(HEAD(1)); stage_qf(HEAD(2)); stage_qf(HEAD(3));
+            stage_qf(HEAD(4)); stage_qf(HEAD(5)); stage_qf(HEAD(6)); stage_qf(HEAD(7));
+            if (T_QF_DBG & (2 | 64 | 128)) {  // debugging: heads 0 and / or 1 applied in the open behind the query stages (as the first tile's prologue does)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (!(T_QF_DBG & 2) && !(T_QF_DBG & (h == 0 ? 64 : 128))) continue;
+                    req_head(op, kvc, h);
+                    VM_WAIT(0);
+                    pin_head(op);
+#pragma unroll
+                    for (int g = 0; g < 12; ++g) apply_ride(qall[QF ? h : 0], g, h == 0 ? apA : apB, S, tile);
+                }
+            }
+        }
+        auto flush_q7 = [&]() {  // QF: the deferred groups of the last query stage
+#pragma unroll
+            for (int i = 0; i < ND; ++i) mfma_group<SP, -1>(hqf[1], wfd[i], xp[QF ? NG + i : 0]);
+        };
+        // QF: Q' of head h + 1 comes from qall, nothing is requested
+#define QC(h1, q_) qall[QF ? (h1) : 0]
+        if constexpr (QF) {
+            stage_merge(HEAD(0), apA, apB, QC(1, qB), QC(1, qA), flush_q7);
+            stage_merge(HEAD(1), apB, apA, QC(2, qA), QC(2, qB), flush_mergeA0);
+            stage_merge(HEAD(2), apA, apB, QC(3, qB), QC(3, qA), flush_mergeB);
+            stage_merge(HEAD(3), apB, apA, QC(4, qA), QC(4, qB), flush_mergeA);
+            stage_merge(HEAD(4), apA, apB, QC(5, qB), QC(5, qA), flush_mergeB);
+            stage_merge(HEAD(5), apB, apA, QC(6, qA), QC(6, qB), flush_mergeA);
+            stage_merge(HEAD(6), apA, apB, QC(7, qB), QC(7, qA), flush_mergeB);
+            stage_merge(HEAD(7), apB, apA, QC(7, qA), QC(7, qB), flush_mergeA);
+        } else {
         //            head   planes  planes of head + 1   Q' consumed (head + 1)   Q' requested (head + 2)   deferred groups of
         stage_merge(HEAD(0), apA, apB, qB, qA, flush_none);   // (the previous tile ended flushed)
         stage_merge(HEAD(1), apB, apA, qA, qB, flush_mergeA0);
@@ -461,12 +583,28 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         stage_merge(HEAD(5), apB, apA, qA, qB, flush_mergeA);
         stage_merge(HEAD(6), apA, apB, qB, qA, flush_mergeB);
         stage_merge(HEAD(7), apB, apA, qA, qB, flush_mergeA);
+        }
+#undef QC
         flush_mergeB();  // norm1 needs the finished accumulators
         vm_wait<PIECES>();  // x segment 7 (requested at the top of stage 7, older than that stage's weight pieces)
         pin_x(xs2);
         add_x(acc[7], xs2, sc.c1);
 
         TSTAMP(1);  // end of the merge phase
+#if T_QF_DUMP  // debugging: y := Q' of the tile (1) / the merge accumulators in front of norm1 (3); the first up stage below drains
+        if constexpr (QF) {
+            float* yd = y + grp + lane * 4;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = T_QF_DUMP == 1 ? qall[QF ? b : 0][a][k] : acc[b][4 * a + k];
+                    *reinterpret_cast<f32x4*>(yd + (b * 4 + a) * 256) = o;
+                }
+        }
+#endif
         // ---- m1 = LayerNorm1(merge + x) (models/transformer.py:84), straight into the B-operand planes of FFN-up ---
         V mp[16][NP];
         {
@@ -663,8 +801,13 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
             stage_down(hpB, hpA, yes, none, ride0, flush_up);
         }
         stage_up(no, none, flush_downB);                           // chunk 31
+        if constexpr (QF) {  // (the next tile's Q' does not exist yet: its first applies ride in its own query stages)
+            stage_down(hpA, hpB, yes, none, ride0, flush_up);
+            stage_down(hpB, hpA, no, none, ride0, flush_downA);
+        } else {
         stage_down(hpA, hpB, yes, none, HEAD(1), flush_up);         // chunk 30, splitting chunk 31; requests head 0 of the block's next tile
         stage_down(hpB, hpA, no, none, HEAD(2), flush_downA);       // chunk 31; applies that head, requests head 1
+        }
         flush_downB();                                              // norm2 needs the finished accumulators
 #undef HEAD
         // Drain: the ring's two stages in flight and head 1 of the next tile, requested two thirds of a stage ago.  That
@@ -673,7 +816,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         // respect to loads, gemm_split.hip; stage 0 of the next tile starts without a vector-memory wait).
         TSTAMP(3);  // end of the last stage
         VM_WAIT(0);
-        if (has_next) {
+        if (!QF && has_next) {
             pin_head(op);
             pin_x(qA);
 #pragma unroll
@@ -717,7 +860,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o[k] = acc[b][4 * a + k] * rstd * g4[k] + b4[k];
                         // one contiguous 1 KiB per wave instruction
-                        if (!(T_ABLATE & (16 | 128)) || o[0] + o[1] + o[2] + o[3] == 123.456f) *reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256) = o;
+                        if ((!(T_ABLATE & (16 | 128)) && !(QF && T_QF_DUMP)) || o[0] + o[1] + o[2] + o[3] == 123.456f) *reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256) = o;
                         o2[a2] = o;
                     }
                     if (NQ) {  // B operand of the query stages below
@@ -854,11 +997,13 @@ __global__ __launch_bounds__(256) void act_layout_kernel(const float* __restrict
 // Wq_next != NULL: eight more stages, chunk j of the next layer's query projection [256][256] laid out like an up stage.
 template <class SP>
 __global__ void pack_tail_kernel(const float* __restrict__ Wm, const float* __restrict__ W1, const float* __restrict__ W2,
-                                 const float* __restrict__ Wq_next, float s_wm, float s_w1, float s_w2, float s_wq,
+                                 const float* __restrict__ Wq_next, int q_first, float s_wm, float s_w1, float s_w2, float s_wq,
                                  typename SP::vec* __restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (TAIL_STAGES + (Wq_next ? NEXT_Q_STAGES : 0)) * 16 * 64) return;
-    const int lane = t & 63, frag = (t >> 6) & 15, stage = t >> 10;
+    const int lane = t & 63, frag = (t >> 6) & 15, stage_out = t >> 10;
+    // q_first: the eight query stages (THIS layer's Wq) come first in the image, the 72 stages of the tail behind them
+    const int stage = !(Wq_next && q_first) ? stage_out : stage_out < NEXT_Q_STAGES ? TAIL_STAGES + stage_out : stage_out - NEXT_Q_STAGES;
     const int m = lane & 31, half = lane >> 5;
     float v[8];
     float s;
@@ -887,7 +1032,7 @@ __global__ void pack_tail_kernel(const float* __restrict__ Wm, const float* __re
 #pragma unroll
     for (int j = 0; j < 8; ++j) SP::split1(SP::SCALED ? v[j] * s : v[j], j, p);
 #pragma unroll
-    for (int pl = 0; pl < SP::NP; ++pl) out[(((int64_t)stage * SP::NP + pl) * 16 + frag) * 64 + lane] = p[pl];
+    for (int pl = 0; pl < SP::NP; ++pl) out[(((int64_t)stage_out * SP::NP + pl) * 16 + frag) * 64 + lane] = p[pl];
 }
 
 constexpr int KVF_THREADS = 320;  // kv_finalize_image_kernel: 264 threads x 4 consecutive elements = the 1 056 of a head
@@ -1008,6 +1153,9 @@ bool tail_scales(const scream_tail_exps_t* ex, TailScales* sc) {
     if (ex->e_y < -40 || ex->e_y > 40 || ex->e_wq < -40 || ex->e_wq > 40) return false;
     sc->s_y = exp2i(ex->e_y);
     sc->cq = exp2i(-ex->e_y - ex->e_wq);
+    if (ex->e_x < -40 || ex->e_x > 40) return false;
+    sc->s_x = exp2i(ex->e_x);
+    sc->cqf = exp2i(-ex->e_x - ex->e_wq);
     return true;
 }
 
@@ -1019,23 +1167,24 @@ extern "C" int64_t scream_tail_image_bytes(int32_t split, int32_t with_next_q) {
 }
 extern "C" int64_t scream_kv_image_bytes(void) { return KV_IMAGE_BYTES; }
 
-extern "C" int scream_pack_tail(const float* Wm, const float* W1, const float* W2, const float* Wq_next, int32_t split,
+extern "C" int scream_pack_tail(const float* Wm, const float* W1, const float* W2, const float* Wq_next, int32_t q_first, int32_t split,
                                 const scream_tail_exps_t* exps, void* image, void* stream) {
     SCREAM_REQUIRE(Wm && W1 && W2 && image && split_ok(split), SCREAM_EINVAL);
     SCREAM_REQUIRE(!Wq_next || split != SCREAM_SPLIT_BF3, SCREAM_EUNSUPPORTED);
+    SCREAM_REQUIRE(!q_first || Wq_next, SCREAM_EINVAL);
     SCREAM_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, SCREAM_EINVAL);
     const dim3 grid((TAIL_STAGES + (Wq_next ? NEXT_Q_STAGES : 0)) * 16 * 64 / 256), block(256);
     if (split != SCREAM_SPLIT_BF3) {
         TailScales sc;
         SCREAM_REQUIRE(tail_scales(exps, &sc), SCREAM_EINVAL);
         if (split == SCREAM_SPLIT_H2)
-            pack_tail_kernel<SplitH2><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, Wq_next, exp2i(exps->e_wm), exp2i(exps->e_w1),
+            pack_tail_kernel<SplitH2><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, Wq_next, q_first, exp2i(exps->e_wm), exp2i(exps->e_w1),
                                                                              exp2i(exps->e_w2), exp2i(exps->e_wq), reinterpret_cast<f16x8*>(image));
         else
-            pack_tail_kernel<SplitH1><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, Wq_next, exp2i(exps->e_wm), exp2i(exps->e_w1),
+            pack_tail_kernel<SplitH1><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, Wq_next, q_first, exp2i(exps->e_wm), exp2i(exps->e_w1),
                                                                              exp2i(exps->e_w2), exp2i(exps->e_wq), reinterpret_cast<f16x8*>(image));
     } else {
-        pack_tail_kernel<SplitBf3><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, nullptr, 1.f, 1.f, 1.f, 1.f, reinterpret_cast<bf16x8*>(image));
+        pack_tail_kernel<SplitBf3><<<grid, block, 0, as_stream(stream)>>>(Wm, W1, W2, nullptr, 0, 1.f, 1.f, 1.f, 1.f, reinterpret_cast<bf16x8*>(image));
     }
     SCREAM_LAUNCH_CHECK();
     return 0;
@@ -1062,11 +1211,11 @@ extern "C" int scream_kv_finalize_image(const float* kv_partial, const int32_t* 
 }
 
 namespace {
-template <class SP, bool NQ>
+template <class SP, bool NQ, bool QF = false>
 void launch_tail(unsigned grid, hipStream_t st, const float* Q, const void* kv_image, const int32_t* tile_cloud, int32_t kv_cloud_offset,
                  const int32_t* cloud_len, const float* x, const void* tail_image, const float* g1, const float* b1, const float* g2,
                  const float* b2, float* y, float* q_next, int tiles, const TailScales& sc) {
-    tail_kernel<SP, NQ><<<dim3(grid), dim3(TT), 0, st>>>(Q, reinterpret_cast<const char*>(kv_image), tile_cloud, kv_cloud_offset, cloud_len, x,
+    tail_kernel<SP, NQ, QF><<<dim3(grid), dim3(TT), 0, st>>>(Q, reinterpret_cast<const char*>(kv_image), tile_cloud, kv_cloud_offset, cloud_len, x,
                                                          reinterpret_cast<const char*>(tail_image), g1, b1, g2, b2, y, q_next, tiles, sc);
 }
 }  // namespace
@@ -1076,7 +1225,9 @@ extern "C" int scream_layer_tail_f32(const float* Q, const void* kv_image, const
                                      const void* tail_image, const float* g1, const float* b1, const float* g2,
                                      const float* b2, float* y, float* q_next, int64_t M, int32_t split,
                                      const scream_tail_exps_t* exps, void* stream) {
-    SCREAM_REQUIRE(Q && kv_image && tile_cloud && cloud_len && x && tail_image && g1 && b1 && g2 && b2 && y && split_ok(split), SCREAM_EINVAL);
+    // Q == NULL: the image was packed with q_first (scream_pack_tail) -- the kernel computes Q' = elu(x . Wq^T) + 1 itself (fp16 splits)
+    SCREAM_REQUIRE(kv_image && tile_cloud && cloud_len && x && tail_image && g1 && b1 && g2 && b2 && y && split_ok(split), SCREAM_EINVAL);
+    SCREAM_REQUIRE(Q || (split != SCREAM_SPLIT_BF3 && !q_next), SCREAM_EINVAL);
     SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0, SCREAM_EUNSUPPORTED);
     SCREAM_REQUIRE(((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(kv_image) | reinterpret_cast<uintptr_t>(x) |
                      reinterpret_cast<uintptr_t>(tail_image) | reinterpret_cast<uintptr_t>(g1) | reinterpret_cast<uintptr_t>(b1) |
@@ -1085,7 +1236,7 @@ extern "C" int scream_layer_tail_f32(const float* Q, const void* kv_image, const
     SCREAM_REQUIRE(x != y, SCREAM_EINVAL);  // the residual of a row is read twice, long after its neighbours were written
     // q_next (the image then has its eight query stages): fp16 splits only; it may be Q itself, never x or y
     SCREAM_REQUIRE(!q_next || (split != SCREAM_SPLIT_BF3 && q_next != x && q_next != y), SCREAM_EINVAL);
-    TailScales sc{1.f, 1.f, 1.f, 1.f, 1e-5f, 1.f, 1.f, 1.f, 1e-5f, 1.f, 1.f};
+    TailScales sc{1.f, 1.f, 1.f, 1.f, 1e-5f, 1.f, 1.f, 1.f, 1e-5f, 1.f, 1.f, 1.f, 1.f};
     if (split != SCREAM_SPLIT_BF3) SCREAM_REQUIRE(tail_scales(exps, &sc), SCREAM_EINVAL);
     const int64_t tiles = M / SCREAM_ROW_TILE;
     if (tiles == 0) return 0;
@@ -1094,9 +1245,13 @@ extern "C" int scream_layer_tail_f32(const float* Q, const void* kv_image, const
     hipStream_t st = as_stream(stream);
 #define TAIL_ARGS grid, st, Q, kv_image, tile_cloud, kv_cloud_offset, cloud_len, x, tail_image, g1, b1, g2, b2, y, q_next, (int)tiles, sc
     if (split == SCREAM_SPLIT_H2) {
-        if (q_next) launch_tail<SplitH2, true>(TAIL_ARGS); else launch_tail<SplitH2, false>(TAIL_ARGS);
+        if (!Q) launch_tail<SplitH2, false, true>(TAIL_ARGS);
+        else if (q_next) launch_tail<SplitH2, true>(TAIL_ARGS);
+        else launch_tail<SplitH2, false>(TAIL_ARGS);
     } else if (split == SCREAM_SPLIT_H1) {
-        if (q_next) launch_tail<SplitH1, true>(TAIL_ARGS); else launch_tail<SplitH1, false>(TAIL_ARGS);
+        if (!Q) launch_tail<SplitH1, false, true>(TAIL_ARGS);
+        else if (q_next) launch_tail<SplitH1, true>(TAIL_ARGS);
+        else launch_tail<SplitH1, false>(TAIL_ARGS);
     } else {
         launch_tail<SplitBf3, false>(TAIL_ARGS);
     }

@@ -124,11 +124,19 @@ class PointTransformer(nn.Module):
     # from two halves instead of four quarters)
     ring_proj = os.environ.get("SCREAM_RING_PROJ", "1") != "0"
 
+    # EXPERIMENTAL, off: every layer tail begins with its OWN query projection (Wq in front of the tail image; csrc/tail_split.hip,
+    # QF) -- Q' is neither written by a projection launch nor read back, the self layers' projection computes key/value chunks only
+    # and the cross layers launch no query projection at all.  Parity-green and +0.8 % on the bench line, but NOT repeatable bit for
+    # bit when other kernels run beside it on a second stream (tools/tail_soak.py kind 3: isolated 32-row groups differ by ~1e-5
+    # between two launches on the same inputs; root cause open, profiles/r04_qf_*.txt), so it is opt-in for experiments only
+    # (SCREAM_Q_FIRST=1) and nothing measured or shipped uses it.
+    q_first = os.environ.get("SCREAM_Q_FIRST", "0") == "1"
+
     def _fused_cfg(self, split) -> bool:
         return bool(split and self.fused_tail)
 
     def _signature(self):
-        return (self.fused_tail, self.batched_cross_kv, self.fuse_next_q, self.ring_proj) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (self.fused_tail, self.batched_cross_kv, self.fuse_next_q, self.ring_proj, self.q_first) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _layer_inputs(self):
         """(in_q, in_kv) per layer of _layer_modules() [+ per layer of _stem_tgt_modules()] and the coordinate MLP's input:
@@ -212,7 +220,8 @@ class PointTransformer(nn.Module):
         tgt_layers = (_lib.LayerT * max(len(tgt_mods), 1))()
         ns = self.self_layer_num
         # the cross layer behind every cross-stage self layer, when its query projection rides in that layer's tail
-        next_cross = {id(mods[i]): i + 1 for i in range(ns, len(mods) - 1, 2)} if (fp16_split and self.fused_tail and self.fuse_next_q) else {}
+        qf = bool(fp16_split and self.fused_tail and self.q_first)  # every tail projects its own queries
+        next_cross = {id(mods[i]): i + 1 for i in range(ns, len(mods) - 1, 2)} if (fp16_split and self.fused_tail and self.fuse_next_q and not qf) else {}
         for L, m, (in_q, in_kv) in list(zip(layers, mods, ins)) + list(zip(tgt_layers, tgt_mods, tgt_ins)):
             # [q | k heads 0-3 | v heads 0-3 | k heads 4-7 | v heads 4-7]: a 256-wide GEMM tile then holds K and V of
             # four heads for the same tokens, which is what the fused K^T V epilogue needs (include/scream_hip.h)
@@ -233,13 +242,20 @@ class PointTransformer(nn.Module):
                 nxt = next_cross[id(m)]
                 wq_next = mods[nxt].q_proj.weight
                 ex.update(e_y=scales.exp_for(scales.ln_bound(*ins[nxt][0])), e_wq=scales.w_exp(wq_next))
+            if qf:  # the block input (a LayerNorm output, bounded by in_q) is the operand of this layer's own q_proj
+                ex.update(e_x=ex["e_xq"], e_wq=scales.w_exp(m.q_proj.weight))
             L.tail_exps = ops.tail_exps(**ex)
             L.tail = None
             L.tail_next_q = int(wq_next is not None)
+            L.tail_q_first, L.proj_kv = int(qf), None
+            if qf and self.ring_proj:  # the projection of such a layer: key/value chunks only
+                pp = ops.pack_proj(wkv.detach().to(device=dev, dtype=torch.float32), 0, split, L.e_wkv)
+                keep.append(pp.data)
+                L.proj_kv = pp.data_ptr()
             if split and self.fused_tail:  # one launch for everything behind the projections (scream_layer_tail_f32)
                 f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32)
                 img = ops.pack_tail(f32(m.merge.weight), f32(m.mlp[0].weight), f32(m.mlp[2].weight), split, L.tail_exps,
-                                    Wq_next=None if wq_next is None else f32(wq_next))
+                                    Wq_next=None if wq_next is None else f32(wq_next), Wq_own=f32(m.q_proj.weight) if qf else None)
                 keep.append(img.data)
                 L.tail = img.data_ptr()
                 L.wm, L.w1, L.w2 = None, None, None

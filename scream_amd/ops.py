@@ -77,6 +77,7 @@ class PackedTail:
     split: int
     exps: _lib.TailExpsT
     next_q: bool = False  # eight more stages: the next layer's query projection (pack_tail(Wq_next=...))
+    q_first: bool = False  # eight more stages IN FRONT: this layer's own query projection (pack_tail(Wq_own=...)); layer_tail(Q=None)
 
     def data_ptr(self) -> int:
         return self.data.data_ptr()
@@ -142,17 +143,23 @@ def gemm_split(A: torch.Tensor, Wp: PackedW, epilogue: int = EPI_NONE, n_act: in
 
 def tail_exps(**kw) -> _lib.TailExpsT:
     e = _lib.TailExpsT()
-    for k in ("e_att", "e_wm", "e_m1", "e_w1", "e_h", "e_w2", "e_y", "e_wq", "e_q"):
+    for k in ("e_att", "e_wm", "e_m1", "e_w1", "e_h", "e_w2", "e_y", "e_wq", "e_x", "e_q"):
         setattr(e, k, int(kw.get(k, 0)))
     return e
 
 
 def pack_tail(Wm: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, split: Optional[int] = None,
-              exps: Optional[_lib.TailExpsT] = None, Wq_next: Optional[torch.Tensor] = None) -> PackedTail:
+              exps: Optional[_lib.TailExpsT] = None, Wq_next: Optional[torch.Tensor] = None,
+              Wq_own: Optional[torch.Tensor] = None) -> PackedTail:
     """merge.weight [256,256], mlp.0.weight [1024,256], mlp.2.weight [256,1024] -> the weight image of layer_tail.
     SPLIT_H2 needs `exps` (scales.layer_exps / ops.tail_exps): the image carries e_wm, e_w1, e_w2, the kernel the rest.
     Wq_next (fp16 splits): q_proj.weight of the NEXT layer -- layer_tail(..., q_next=...) then also produces that layer's Q'
-    (exps.e_y: exponent of this block's output as an operand, exps.e_wq: of Wq_next)."""
+    (exps.e_y: exponent of this block's output as an operand, exps.e_wq: of Wq_next).
+    Wq_own (fp16 splits, instead of Wq_next): q_proj.weight of THIS layer, its stages in front -- layer_tail(Q=None, ...) then computes
+    Q' = elu(x Wq^T) + 1 itself (exps.e_x: exponent of the block input x as an operand, exps.e_wq: of Wq_own)."""
+    assert Wq_next is None or Wq_own is None
+    q_first = Wq_own is not None
+    Wq_next = Wq_own if q_first else Wq_next
     split = default_split() if split is None else split
     Wm, W1, W2 = (w.detach().to(torch.float32).contiguous() for w in (Wm, W1, W2))
     assert Wm.shape == (D_MODEL, D_MODEL) and W1.shape == (4 * D_MODEL, D_MODEL) and W2.shape == (D_MODEL, 4 * D_MODEL)
@@ -167,8 +174,8 @@ def pack_tail(Wm: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, split: Optio
     if nbytes < 0:
         raise _lib.ScreamHipError("scream_tail_image_bytes returned %d (a next-layer query projection needs an fp16 split)" % nbytes)
     out = torch.empty(nbytes, device=Wm.device, dtype=torch.uint8)
-    check(lib.scream_pack_tail(_p(Wm), _p(W1), _p(W2), _p(Wq_next), split, C.byref(exps), _p(out, torch.uint8), _stream()), "scream_pack_tail")
-    return PackedTail(out, split, exps, Wq_next is not None)
+    check(lib.scream_pack_tail(_p(Wm), _p(W1), _p(W2), _p(Wq_next), int(q_first), split, C.byref(exps), _p(out, torch.uint8), _stream()), "scream_pack_tail")
+    return PackedTail(out, split, exps, Wq_next is not None and not q_first, q_first)
 
 
 def kv_finalize_image(partial: torch.Tensor, cloud_row0, cloud_len, row_base: int, cloud_begin: int, n_kv: int,
@@ -194,11 +201,12 @@ def layer_tail(Q: torch.Tensor, kv_image: torch.Tensor, tile_cloud, kv_cloud_off
     """Attention apply + merge + norm1 + FFN + norm2 of one block in one launch (scream_layer_tail_f32).
     Q, x and the result are FRAGMENT-major [M,256] matrices (act_layout converts).  q_next (images packed with Wq_next): also
     receives elu(y Wq_next^T) + 1, fragment-major; it may be Q itself."""
-    M = Q.shape[0]
-    assert Q.shape[1] == D_MODEL and x.shape == Q.shape
+    M = x.shape[0]
+    assert x.shape[1] == D_MODEL and (Q is None or x.shape == Q.shape)
+    assert (Q is None) == tail.q_first, "Q = None goes with an image that carries this layer's own query stages (pack_tail(Wq_own=...))"
     assert (q_next is not None) == tail.next_q, "q_next goes with an image that carries the next layer's query stages"
     if out is None:
-        out = torch.empty(M, D_MODEL, device=Q.device, dtype=torch.float32)
+        out = torch.empty(M, D_MODEL, device=x.device, dtype=torch.float32)
     check(_lib.load().scream_layer_tail_f32(_p(Q), _p(kv_image, torch.uint8), _p(tile_cloud, torch.int32),
                                             kv_cloud_offset, _p(cloud_len, torch.int32), _p(x),
                                             tail.data_ptr(), _p(g1), _p(b1), _p(g2), _p(b2), _p(out), _p(q_next),

@@ -955,6 +955,61 @@ def test_fused_layer_tail_many_tiles_equals_unfused_path(split):
     assert torch.equal(ops.layer_tail(Qf, kvi, tc, 0, clen, xf, img, g1, b1, g2, b2), yf)  # deterministic
 
 
+@pytest.mark.parametrize("cross", [False, True])
+def test_layer_tail_with_its_own_query_projection(cross):
+    """tail_kernel<SplitH2, QF>: the image carries THIS layer's Wq in front and every tile begins with Q' = elu(x Wq^T) + 1 of its own
+    rows, kept in registers for the applies (no Q' in memory; scream_layer_tail_f32 with Q == NULL) -- against the kernel that reads the
+    projection's Q' (same products, another summation order inside the matrix unit: fp32-rounding-level agreement of y) and against the
+    oracle block, 258 row tiles on 256 persistent blocks, ragged clouds; a cross block takes its keys from other clouds."""
+    g_ = torch.Generator().manual_seed(9)
+    n_clouds, rows = 24, 33024
+    bounds = torch.linspace(0, rows // 128, n_clouds + 1).round().int()
+    lens, row0, tiles = [], [], []
+    for c in range(n_clouds):
+        t0, t1 = int(bounds[c]), int(bounds[c + 1])
+        row0.append(t0 * 128)
+        lens.append((t1 - t0) * 128 - int(torch.randint(0, 127, (1,), generator=g_)))
+        tiles += [c] * (t1 - t0)
+    x = torch.randn(rows, 256, generator=g_)
+    sd = make_state_dict(8, 256, 1, 1)
+    pre = "stem.0."
+    q, k, v = (sd[pre + "%s_proj.weight" % n] for n in "qkv")
+    W = torch.cat([q, k[:128], v[:128], k[128:], v[128:]], dim=0)
+    tc, crow0, clen = dev(torch.tensor(tiles, dtype=torch.int32)), dev(torch.tensor(row0, dtype=torch.int32)), dev(torch.tensor(lens, dtype=torch.int32))
+    g1, b1, g2, b2 = (dev(sd[pre + n]) for n in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"))
+    xf = ops.act_layout(dev(x), True)
+    SPL = ops.SPLIT_H2
+    a_exp = scales.exp_for(float(x.abs().max()))
+    Qf, part = ops.gemm_qkv(xf, ops.pack_w(dev(W), SPL), 256, tc, crow0, clen, 0, ops.LAYOUT_A_FRAG | ops.LAYOUT_C_FRAG, a_exp=a_exp)
+    kvi = ops.kv_finalize_image(part, crow0, clen, 0, 0, n_clouds, n_clouds, split=SPL)
+    off = 0
+    if cross:  # every tile attends to the NEXT cloud's keys (kv_cloud_offset 1; the last cloud wraps onto an extra copy of image 0)
+        kvi = torch.cat([kvi, kvi[:1]])
+        clen = torch.cat([clen, clen[:1]])
+        off = 1
+    exd = scales.tail_exps(sd[pre + "merge.weight"], sd[pre + "mlp.0.weight"], sd[pre + "mlp.2.weight"], sd[pre + "norm1.weight"],
+                           sd[pre + "norm1.bias"], float((x @ v.t()).abs().max()) * 1.01, float((x @ q.t()).abs().max()) * 1.01)
+    mats = [dev(sd[pre + n]) for n in ("merge.weight", "mlp.0.weight", "mlp.2.weight")]
+    plain = ops.pack_tail(*mats, SPL, ops.tail_exps(**exd))
+    y_plain = ops.layer_tail(Qf, kvi, tc, off, clen, xf, plain, g1, b1, g2, b2)
+    own = ops.pack_tail(*mats, SPL, ops.tail_exps(e_x=a_exp, e_wq=scales.w_exp(q), **exd), Wq_own=dev(q))
+    assert own.q_first and own.data.numel() == plain.data.numel() + 8 * 2 * 16 * 1024
+    y_own = ops.layer_tail(None, kvi, tc, off, clen, xf, own, g1, b1, g2, b2)
+    valid = torch.zeros(rows, dtype=torch.bool)
+    for r0, n in zip(row0, lens):
+        valid[r0:r0 + n] = True
+    a, b = ops.act_layout(y_own, False).cpu(), ops.act_layout(y_plain, False).cpu()
+    torch.testing.assert_close(a[valid], b[valid], rtol=2e-5, atol=2e-5)
+    assert torch.equal(ops.layer_tail(None, kvi, tc, off, clen, xf, own, g1, b1, g2, b2), y_own)  # deterministic
+    if not cross:  # and the oracle block on one cloud
+        r0, n = row0[3], lens[3]
+        want = O.mh_attention(x[r0:r0 + n][None], x[r0:r0 + n][None], x[r0:r0 + n][None], sd, pre)[0]
+        torch.testing.assert_close(a[r0:r0 + n], want, rtol=2e-4, atol=5e-5)
+    from scream_amd._lib import ScreamHipError
+    with pytest.raises(ScreamHipError):  # the bf16 split has no such image
+        ops.pack_tail(*mats, ops.SPLIT_BF3, None, Wq_own=dev(q))
+
+
 def test_layer_tail_with_the_next_layers_query_projection():
     """tail_kernel<SplitH2, NQ>: the image carries Wq of the NEXT layer and every tile ends with Q'_next = elu(y Wq^T) + 1 written
     over its own rows of Q (258 row tiles on 256 persistent blocks, ragged clouds).  y is bit-identical to the plain kernel's;
@@ -1020,10 +1075,31 @@ def test_forward_with_and_without_the_fused_query_projection(golden):
         net = PointTransformer(256, 2, 2)
         net.load_state_dict(sd)
         net = net.to("cuda:0").eval()
-        net.fuse_next_q = on
+        net.fuse_next_q, net.q_first = on, False  # (the experimental q_first would replace the next-layer query stages)
         outs[on] = net.forward_batch([dev(src)], [dev(tgt)])[0].cpu()
         layers = net._pack_weights().layers[0]
         assert [int(L.tail_next_q) for L in layers] == ([0, 0, 1, 0, 1, 0] if on else [0] * 6)
+    torch.testing.assert_close(outs[True], outs[False], rtol=2e-5, atol=2e-6)
+
+
+def test_forward_with_and_without_the_tails_own_query_projection(golden):
+    """PointTransformer.q_first (experimental, off by default: scream_amd/model.py): every layer tail begins with its own query projection, the self layers'
+    projection launches compute key/value chunks only, the cross layers launch none on the query side.  Same products either way; the two
+    forwards agree to fp32 rounding (both are held to the reference golden by test_forward_vs_reference_golden)."""
+    from scream_amd.model import PointTransformer
+    sd = make_state_dict(0, 256, 2, 2)
+    g_ = torch.Generator().manual_seed(2)
+    src, tgt = torch.rand(700, 3, generator=g_) - 0.5, torch.rand(900, 3, generator=g_) - 0.5
+    outs = {}
+    for on in (True, False):
+        net = PointTransformer(256, 2, 2)
+        net.load_state_dict(sd)
+        net = net.to("cuda:0").eval()
+        net.q_first = on
+        outs[on] = net.forward_batch([dev(src)], [dev(tgt)])[0].cpu()
+        layers = net._pack_weights().layers[0]
+        assert [int(L.tail_q_first) for L in layers] == [int(on)] * 6
+        assert all((L.proj_kv is not None) == on for L in layers)
     torch.testing.assert_close(outs[True], outs[False], rtol=2e-5, atol=2e-6)
 
 

@@ -438,8 +438,8 @@ def test_no_instruction_touches_a_register_whose_asm_load_is_pending(tmp_path):
                 # Full drains are allowed only at the tile boundaries (five of them at the time of writing).
                 assert not any(re.match(r"\s*scratch_", l) for l in body), "scratch traffic in " + want
                 drains = sum(1 for l in body if re.match(r"\s*s_waitcnt vmcnt\(0\)", l))
-                assert drains <= 8, drains
-        assert n_kernels == {"gemm_split.hip": 36, "tail_split.hip": 5}[src]  # every operand split of each (the tail: + the two fp16 splits with the next layer's query stages)
+                assert drains <= 10, drains  # (QF: the x rows of a tile are loaded and split in the open at its start -- four more, all in front of the tile's first barrier)
+        assert n_kernels == {"gemm_split.hip": 36, "tail_split.hip": 7}[src]  # every operand split of each (the tail: + the two fp16 splits with the next layer's query stages, + the same two with the layer's own query stages in front)
 
 
 def test_the_static_checker_detects_what_it_is_there_for():
@@ -517,7 +517,7 @@ def test_tuning_builds_are_verified_before_they_can_be_launched(tmp_path):
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import asm_inflight_check as chk
     src = os.path.join(REPO, "scream_amd", "csrc", "tail_split.hip")
-    assert chk.verify_source(src, ["-ffp-contract=off", "-DT_ABLATE=1"], str(tmp_path / "t1.s"), "11tail_kernelINS_7SplitH2ELb0") == 1  # (the instance the tuning tools launch)
+    assert chk.verify_source(src, ["-ffp-contract=off", "-DT_ABLATE=1"], str(tmp_path / "t1.s"), "11tail_kernelINS_7SplitH2ELb0ELb0") == 1  # (the instance the tuning tools launch)
     bad = tmp_path / "bad.hip"  # a register load consumed behind a wait that does not cover it
     bad.write_text("""#include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -23,7 +23,7 @@ def build():
     procs = []
     for bits, label in VARIANTS:
         flags = ["-ffp-contract=off", "-DT_ABLATE=%d" % bits, *EXTRA]
-        want = "11tail_kernelINS_" + {"h2": "7SplitH2ELb0", "x3": "8SplitBf3ELb0"}[os.environ.get("T_SPLIT", "h2")]  # the instance `run` will launch
+        want = "11tail_kernelINS_" + {"h2": "7SplitH2ELb0ELb0", "x3": "8SplitBf3ELb0ELb0"}[os.environ.get("T_SPLIT", "h2")]  # the instance `run` will launch
         try:
             assert chk.verify_source(SRC, flags, os.path.join(OUT, "t_%d.s" % bits), want) >= 1
         except RuntimeError as e:  # never launch a variant whose generated code touches a pending register: skip it, loudly

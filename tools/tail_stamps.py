@@ -13,7 +13,7 @@ def build():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     src = os.path.join(ROOT, "scream_amd/csrc/tail_split.hip")
     flags = ["-ffp-contract=off", "-DT_STAMPS", *os.environ.get("T_EXTRA", "").split()]
-    want = "11tail_kernelINS_" + {"h2": "7SplitH2ELb0", "x3": "8SplitBf3ELb0"}[os.environ.get("T_SPLIT", "h2")]  # the instance `run` launches
+    want = "11tail_kernelINS_" + {"h2": "7SplitH2ELb0ELb0", "x3": "8SplitBf3ELb0ELb0"}[os.environ.get("T_SPLIT", "h2")]  # the instance `run` launches
     assert chk.verify_source(src, flags, SO[:-3] + ".s", want) >= 1  # raises if a stamp pushed a pending register around
     subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", *flags, src, "-o", SO])
 
