@@ -592,15 +592,15 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
 
         TSTAMP(1);  // end of the merge phase
 #if T_QF_DUMP  // debugging: y := Q' of the tile (1) / the merge accumulators in front of norm1 (3); the first up stage below drains
-        if constexpr (QF) {
-            float* yd = y + grp + lane * 4;
+        if (QF && (T_QF_DUMP < 4 || q_next)) {  // (4 / 5: the same two quantities into q_next, y stored as usual)
+            float* yd = (T_QF_DUMP < 4 ? y : q_next) + grp + lane * 4;
 #pragma unroll
             for (int b = 0; b < 8; ++b)
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     f32x4 o;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = T_QF_DUMP == 1 ? qall[QF ? b : 0][a][k] : acc[b][4 * a + k];
+                    for (int k = 0; k < 4; ++k) o[k] = (T_QF_DUMP & 1) ? qall[QF ? b : 0][a][k] : acc[b][4 * a + k];
                     *reinterpret_cast<f32x4*>(yd + (b * 4 + a) * 256) = o;
                 }
         }
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o[k] = acc[b][4 * a + k] * rstd * g4[k] + b4[k];
                         // one contiguous 1 KiB per wave instruction
-                        if ((!(T_ABLATE & (16 | 128)) && !(QF && T_QF_DUMP)) || o[0] + o[1] + o[2] + o[3] == 123.456f) *reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256) = o;
+                        if ((!(T_ABLATE & (16 | 128)) && !(QF && T_QF_DUMP && T_QF_DUMP < 4)) || o[0] + o[1] + o[2] + o[3] == 123.456f) *reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256) = o;
                         o2[a2] = o;
                     }
                     if (NQ) {  // B operand of the query stages below
@@ -1227,7 +1227,7 @@ extern "C" int scream_layer_tail_f32(const float* Q, const void* kv_image, const
                                      const scream_tail_exps_t* exps, void* stream) {
     // Q == NULL: the image was packed with q_first (scream_pack_tail) -- the kernel computes Q' = elu(x . Wq^T) + 1 itself (fp16 splits)
     SCREAM_REQUIRE(kv_image && tile_cloud && cloud_len && x && tail_image && g1 && b1 && g2 && b2 && y && split_ok(split), SCREAM_EINVAL);
-    SCREAM_REQUIRE(Q || (split != SCREAM_SPLIT_BF3 && !q_next), SCREAM_EINVAL);
+    SCREAM_REQUIRE(Q || (split != SCREAM_SPLIT_BF3 && (!q_next || T_QF_DUMP >= 4)), SCREAM_EINVAL);
     SCREAM_REQUIRE(M >= 0 && M % SCREAM_ROW_TILE == 0, SCREAM_EUNSUPPORTED);
     SCREAM_REQUIRE(((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(kv_image) | reinterpret_cast<uintptr_t>(x) |
                      reinterpret_cast<uintptr_t>(tail_image) | reinterpret_cast<uintptr_t>(g1) | reinterpret_cast<uintptr_t>(b1) |

@@ -58,6 +58,17 @@ while time.time() - t0 < secs:
                 y1 = ops.layer_tail(qa, kvi, tc, 0, cl, xf, IMG_Q, g1, b1, g2, b2, q_next=qa)
                 y2 = ops.layer_tail(qb, kvi, tc, 0, cl, xf, IMG_Q, g1, b1, g2, b2, q_next=qb)
                 qref = ops.gemm_split(y1, PQN, ops.EPI_ELU1, n_act=256, layout=FR, a_exp=E_Y)
+            elif kind == 3 and os.environ.get("T_DUMP") == "1":  # T_QF_DUMP = 4 / 5 builds: an intermediate of every tile into q_next
+                IMG_F.next_q = True
+                d1, d2 = torch.zeros_like(xf), torch.zeros_like(xf)
+                y1 = ops.layer_tail(None, kvi, tc, 0, cl, xf, IMG_F, g1, b1, g2, b2, q_next=d1)
+                y2 = ops.layer_tail(None, kvi, tc, 0, cl, xf, IMG_F, g1, b1, g2, b2, q_next=d2)
+                if not torch.equal(y1, y2):
+                    ry = (ops.act_layout(y1, False) != ops.act_layout(y2, False)).any(dim=1).nonzero().flatten().cpu().numpy()
+                    dd = (ops.act_layout(d1, False) != ops.act_layout(d2, False))
+                    rd = dd.any(dim=1).nonzero().flatten().cpu().numpy(); fd = dd.any(dim=0).nonzero().flatten().cpu().numpy()
+                    print("DUMP tiles=%d: y differs in %d rows (first %d); the dumped intermediate differs in %d rows (first %s), %d features, chunks %s, max %.3g"
+                          % (M // 128, len(ry), ry[0], len(rd), rd[:1], len(fd), np.unique(fd // 32), float((d1 - d2).abs().max())), flush=True)
             elif kind == 3:
                 y1 = ops.layer_tail(None, kvi, tc, 0, cl, xf, IMG_F, g1, b1, g2, b2)
                 y2 = ops.layer_tail(None, kvi, tc, 0, cl, xf, IMG_F, g1, b1, g2, b2)
