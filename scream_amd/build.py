@@ -104,6 +104,10 @@ def build(force: bool = False, verbose: bool = False, out: str = None) -> str:
             if sd:
                 raise RuntimeError("%s: %s overwrites the data of a wide store %d wait states behind it (%s ; %s)"
                                    % (src, name, sd[0][3], sd[0][1], sd[0][2]))
+            mh = chk.check_mfma_asm_read_hazard(name, body)
+            if mh:
+                raise RuntimeError("%s: %s reads a matrix-instruction result with an asm vector instruction %d wait states behind it "
+                                   "(%s ; %s)" % (src, name, mh[0][3], mh[0][2], mh[0][1]))
             hz = chk.check_scalar_base_hazard(name, body)
             if hz:
                 raise RuntimeError("%s: %s uses a scalar base %d wait states after a VALU write of it (%s -> %s)"

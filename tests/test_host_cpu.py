@@ -431,6 +431,8 @@ def test_no_instruction_touches_a_register_whose_asm_load_is_pending(tmp_path):
             # ... nor does a VALU instruction overwrite the data registers of a wide asm store right behind it (wrong dwords in
             # a quarter of the lanes, also round 2)
             assert not chk.check_store_data_hazard(name, body), name
+            # ... nor does an asm vector instruction read a matrix-instruction result inside the window hipcc would have padded
+            assert not chk.check_mfma_asm_read_hazard(name, body), name
             if src == "tail_split.hip":
                 # The layer tail keeps NO scratch: a spilled value that is reloaded inside a stage puts a vmcnt(0) in front
                 # of its use (hipcc cannot order a scratch reload against the LDS-DMA in flight) and drains the weight ring
@@ -504,6 +506,17 @@ def test_the_static_checker_detects_what_it_is_there_for():
     assert len(chk.check_store_data_hazard("k", sd)) == 1
     assert not chk.check_store_data_hazard("k", lines("global_store_dwordx4 v240, v[0:3], s[0:1]\ns_nop 1\nv_mov_b32_e32 v1, 0"))
     assert not chk.check_store_data_hazard("k", lines("global_store_dword v240, v1, s[0:1]\nv_mov_b32_e32 v1, 0"))  # 32-bit data: none
+    # (4) an asm vector instruction reading a matrix-instruction result (VGPR form) too close behind it
+    mh = lines("""
+        v_mfma_f32_32x32x16_f16 v[0:15], v[40:43], a[120:123], v[0:15]
+        s_nop 7
+        v_fma_mixlo_f16 v48, v3, s50, 0
+    """)
+    assert len(chk.check_mfma_asm_read_hazard("k", mh)) == 1
+    assert not chk.check_mfma_asm_read_hazard("k", lines("v_mfma_f32_32x32x16_f16 v[0:15], v[40:43], a[120:123], v[0:15]\ns_nop 7\ns_nop 7\ns_nop 7\nv_fma_mixlo_f16 v48, v3, s50, 0"))
+    # a compiler-known instruction in between that rewrites the register (it is padded by hipcc) clears it; AGPR results are read through v_accvgpr_read
+    assert not chk.check_mfma_asm_read_hazard("k", lines("v_mfma_f32_32x32x16_f16 v[0:15], v[40:43], a[120:123], v[0:15]\nv_mul_f32_e32 v3, v3, v3\nv_fma_mixlo_f16 v48, v3, s50, 0"))
+    assert not chk.check_mfma_asm_read_hazard("k", lines("v_mfma_f32_32x32x16_f16 a[0:15], v[40:43], v[44:47], a[0:15]\nv_fma_mixlo_f16 v48, v3, s50, 0"))
 
 
 def test_tuning_builds_are_verified_before_they_can_be_launched(tmp_path):

@@ -7,7 +7,8 @@ spill or reuse such a register before the wait -- silently reading stale bytes. 
 program order with the in-order model of the vector-memory queue (loads, LDS-DMA and stores retire oldest first;
 `vmcnt(N)` leaves the N youngest outstanding) and reports every instruction that touches a VGPR whose load is still
 outstanding.  Second check (check_scalar_base_hazard): the wait states hipcc does not insert in front of an asm memory
-instruction whose scalar base was just written by a VALU instruction.
+instruction whose scalar base was just written by a VALU instruction.  Third and fourth: the data registers of a wide asm
+store, and asm vector instructions that read a matrix-instruction result (check_store_data_hazard, check_mfma_asm_read_hazard).
 
     python tools/asm_inflight_check.py file.s [kernel-name-substring]
 """
@@ -179,6 +180,43 @@ def check_store_data_hazard(name, body, need=2):
     return bad
 
 
+ASM_VALU = re.compile(r"v_fma_mix(lo|hi)_f16\b|v_max_f32(_e32|_e64)? v\d+, 0, v\d+")  # the vector instructions the kernels write as inline asm
+
+
+def check_mfma_asm_read_hazard(name, body, need=20):
+    """A vector instruction that reads a VGPR written by a matrix instruction must be `need` wait states behind it (up to 18 for the
+    16-pass ones; no hardware interlock).  hipcc pads the instructions it knows; GCNHazardRecognizer does not look inside inline asm.
+    With accumulators in AGPRs a compiler-known v_accvgpr_read sits in between; proj_ring.hip is built with MFMA results in VGPRs
+    and its rides read them through asm v_fma_mix.  Every intervening instruction counts as one wait state (a lower bound), in
+    program order."""
+    ins = []
+    for raw in body:
+        t = raw.split(";")[0].strip()
+        if not t or t.startswith(".") or t.endswith(":"):
+            continue
+        ins.append(t)
+    last = {}  # VGPR -> (index, text) of the matrix instruction that wrote it last
+    bad = []
+    for i, t in enumerate(ins):
+        o = t.split()[0]
+        ops = t[len(o):].split(",")
+        if o.startswith("v_mfma") or o.startswith("v_smfmac"):
+            for r in regs_of(ops[0]):
+                if r < ACC:
+                    last[r] = i
+            continue
+        if ASM_VALU.match(t):
+            for r in regs_of(",".join(ops[1:])):
+                if r in last:
+                    ws = sum((int(ins[k].split()[1]) + 1) if ins[k].startswith("s_nop") else 1 for k in range(last[r] + 1, i))
+                    if ws < need:
+                        bad.append((i, t, ins[last[r]], ws))
+        if o.startswith(("v_", "ds_read", "ds_load", "global_load", "buffer_load")) and ops and ops[0].strip():
+            for r in regs_of(ops[0]):
+                last.pop(r, None)
+    return bad
+
+
 def kernels(path):
     lines = open(path).read().splitlines()
     starts = [(i, l.split(":")[0]) for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
@@ -206,6 +244,9 @@ def verify_source(src, flags, out_s, want=""):
             continue
         n += 1
         bad, hz, sd = check_kernel(nm, body), check_scalar_base_hazard(nm, body), check_store_data_hazard(nm, body)
+        mh = check_mfma_asm_read_hazard(nm, body)
+        if mh:
+            raise RuntimeError("%s %s: %s reads a matrix-instruction result with an asm vector instruction %d wait states behind it (%s ; %s)" % (src, flags, nm, mh[0][3], mh[0][2], mh[0][1]))
         if bad:
             raise RuntimeError("%s %s: %s touches a register whose asm load is still in flight (%d places, first: %s)" % (src, flags, nm, len(bad), bad[0][1]))
         if hz:
@@ -228,6 +269,10 @@ def main():
         for n, line, regs in bad[:12]:
             print("   +%d  %s   <- pending v%s" % (n, line, regs))
         total += len(bad)
+        mh = check_mfma_asm_read_hazard(nm, body)
+        if mh:
+            print("   %d asm reads of a matrix-instruction result fewer than 20 wait states behind it, first: %s ; %s (%d)" % (len(mh), mh[0][2], mh[0][1], mh[0][3]))
+            total += len(mh)
         hz = check_scalar_base_hazard(nm, body)
         if hz:
             print("   %d scalar-base hazards (VALU writes an SGPR < 5 wait states before a memory instruction uses it):" % len(hz))
