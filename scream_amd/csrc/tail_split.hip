@@ -490,6 +490,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
             {
                 f32x4 raw[8][4];  // the wave's 32 rows: piece a of segment blk = one contiguous 1 KiB per wave instruction
                 const float* xg = xres + grp + lane * 4;
+                if (T_QF_DBG & 256) VM_WAIT(0);  // (the previous tile's 32 y stores: never more than 32 operations in the queue)
 #pragma unroll
                 for (int blk = 0; blk < 8; ++blk)
 #pragma unroll

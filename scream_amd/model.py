@@ -221,6 +221,10 @@ class PointTransformer(nn.Module):
         ns = self.self_layer_num
         # the cross layer behind every cross-stage self layer, when its query projection rides in that layer's tail
         qf = bool(fp16_split and self.fused_tail and self.q_first)  # every tail projects its own queries
+        if qf:
+            import warnings
+            warnings.warn("scream_amd: q_first is experimental -- its layer-tail kernel is not repeatable bit for bit when other kernels run "
+                          "beside it (profiles/r04_qf_experiment.txt); do not use it for results")
         next_cross = {id(mods[i]): i + 1 for i in range(ns, len(mods) - 1, 2)} if (fp16_split and self.fused_tail and self.fuse_next_q and not qf) else {}
         for L, m, (in_q, in_kv) in list(zip(layers, mods, ins)) + list(zip(tgt_layers, tgt_mods, tgt_ins)):
             # [q | k heads 0-3 | v heads 0-3 | k heads 4-7 | v heads 4-7]: a 256-wide GEMM tile then holds K and V of
