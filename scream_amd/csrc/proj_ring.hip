@@ -42,6 +42,9 @@
 #ifndef P_LB
 #define P_LB 2  // x segments per load batch at a tile boundary (two batches in flight)
 #endif
+#ifndef P_NT
+#define P_NT 3  // non-temporal hint on: 1 the x row loads, 2 the Q' stores, 4 the K^T V partial stores
+#endif
 #ifndef P_ABLATE
 #define P_ABLATE 0  // tuning aid (SCREAM_HIPCC_EXTRA builds): 1 no rides (epilogues dropped), 2 no MFMA, 8 no W DMA after the first two stages (-DT_ABLATE=4: no LDS fragment reads);
                     // inside the rides: 32 elu + 1 without its exponential, 64 no Q' stores, 128 no K'^T V products, 256 no operand splits of K' and V, 512 no slab / partial traffic
@@ -138,7 +141,8 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
             for (int k = 0; k < LB; ++k)
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
-                    raw[b & 1][k][a] = *reinterpret_cast<const f32x4*>(g + rg * 8192 + ((blk0 + k) * 4 + a) * 256);
+                    raw[b & 1][k][a] = (P_NT & 1) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + rg * 8192 + ((blk0 + k) * 4 + a) * 256))
+                                                  : *reinterpret_cast<const f32x4*>(g + rg * 8192 + ((blk0 + k) * 4 + a) * 256);
         };
         request(0);
 #pragma unroll
@@ -255,7 +259,8 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         const f32x4 o = {t[rg][4 * a], t[rg][4 * a + 1], t[rg][4 * a + 2], t[rg][4 * a + 3]};
-                        *reinterpret_cast<f32x4*>(q_pend + rg * 8192 + a * 256) = o;
+                        if (P_NT & 2) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(q_pend + rg * 8192 + a * 256));
+                        else *reinterpret_cast<f32x4*>(q_pend + rg * 8192 + a * 256) = o;
                     }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -314,7 +319,8 @@ __global__ __launch_bounds__(TT, 1) void proj_ring_kernel(ProjArgs pa) {
         const int i = (wave & 1) * 64 + lane + 128 * g;
         if (i < P_KV_ELEMS && part_pend_ok && !(P_ABLATE & 512)) {
             const float* s2 = slabs + (wave & ~1) * P_KV_ELEMS + i;
-            part_pend[i] = s2[0] + s2[P_KV_ELEMS];
+            if (P_NT & 4) __builtin_nontemporal_store(s2[0] + s2[P_KV_ELEMS], part_pend + i);
+            else part_pend[i] = s2[0] + s2[P_KV_ELEMS];
         }
     };
 

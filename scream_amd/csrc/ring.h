@@ -116,10 +116,16 @@ __device__ __forceinline__ void mfma_group(f32x16& acc, const typename SP::vec (
 // kernel's query-only variant: memory fault).  tools/asm_inflight_check.py verifies the wait states on the generated code of
 // every kernel that uses these helpers, at every build (scream_amd/build.py refuses to link otherwise; the CPU suite asserts).
 // four loads STEP bytes apart: the pieces a = 0 .. 3 of a fragment-major segment (1 KiB) or of a lane's 128-byte segment (32 B)
-template <int STEP>
+// NT: the non-temporal hint (rows that stream through once: the L2 then keeps the weight image instead of them)
+template <int STEP, bool NT = false>
 __device__ __forceinline__ void ld_asm4(f32x4 (&d)[4], const void* sbase, unsigned voff) {
     static_assert(STEP == 1024 || STEP == 32, "");
-    if (STEP == 1024) {
+    if (STEP == 1024 && NT) {
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(d[0]) : "v"(voff), "s"(sbase));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 nt" : "=v"(d[1]) : "v"(voff), "s"(sbase));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048 nt" : "=v"(d[2]) : "v"(voff), "s"(sbase));
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072 nt" : "=v"(d[3]) : "v"(voff), "s"(sbase));
+    } else if (STEP == 1024) {
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d[0]) : "v"(voff), "s"(sbase));
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(d[1]) : "v"(voff), "s"(sbase));
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(d[2]) : "v"(voff), "s"(sbase));

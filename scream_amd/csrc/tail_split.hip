@@ -64,6 +64,12 @@
 #ifndef T_RIDE0
 #define T_RIDE0 3  // SplitH2: first MFMA group of a down stage that carries a relu / split pair of the ride (eight groups from there); 0 / 3 / 6: 1.044 / 1.040 / 1.041 ms per 333 k-row launch (profiles/r04_tail_ride0_ab.txt)
 #endif
+#ifndef T_STASH
+#define T_STASH 3  // x segments kept in LDS between their two reads (fp16 kernels; 0: every segment is read twice from memory)
+#endif
+#ifndef T_NT
+#define T_NT 7  // non-temporal hint on: 1 the Q' loads, 2 the y (and next-layer Q') stores, 4 the second (last) read of the x rows, 8 their first read
+#endif
 #ifndef T_QF_DUMP
 #define T_QF_DUMP 0
 #endif
@@ -192,7 +198,11 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
     // of three fp16 products.
     constexpr int ND = SP::NPROD >= 6 ? 1 : T_DEFER_H2;
     constexpr int NG = 16 - ND;  // groups issued inside their own stage
-    __shared__ __attribute__((aligned(16))) char smem[T_SLOTS * STAGE + 4096];  // the ring + the norm parameters, the ONLY LDS object
+    // x segments 0 .. NSTASH - 1 of the tile stay in LDS between their first read (the norm1 residual, merge stages) and their second
+    // (the norm2 residual, FFN): 16 KiB per segment and block, per-wave private (no synchronisation), in the LDS the two-plane rings
+    // leave free -- 3/8 of the second read of x never reaches the L2 / HBM (round 4: the review's traffic item)
+    constexpr int NSTASH = (NP == 2 && !QF) ? T_STASH : 0;
+    __shared__ __attribute__((aligned(16))) char smem[T_SLOTS * STAGE + 4096 + NSTASH * 16384];  // the ring + the norm parameters + the stash, the ONLY LDS object
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
@@ -201,6 +211,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
     // issued before it and waits with vmcnt(0) -- a full store round trip per group of rows (tools/tail_stamps.py: 11.8 k
     // cycles for norm2 + stores).  From LDS the y stores are fire-and-forget.  (SplitH2: gamma1 / beta1 carry m1's 2^e.)
     float* lnp = reinterpret_cast<float*>(smem + T_SLOTS * STAGE);
+    f32x4* stash = reinterpret_cast<f32x4*>(smem + T_SLOTS * STAGE + 4096 + wave * (NSTASH * 4096)) + lane;  // [segment][piece a][lane]
     lnp[tid] = SP::SCALED ? g1[tid] * sc.s_m1 : g1[tid];
     lnp[256 + tid] = SP::SCALED ? b1[tid] * sc.s_m1 : b1[tid];
     lnp[512 + tid] = g2[tid];
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
     auto req_q = [&](f32x4 (&qb)[4], int64_t grp, int h) {  // Q' of head h: the one operand that comes from HBM
         if (T_ABLATE & (16 | 32)) return;
         if (T_ABLATE & 2048) grp = (int64_t)wave * 32 * SCREAM_D_MODEL;  // tuning aid: always the first tile's rows (cache hits)
-        ld_asm4<1024>(qb, seg_base(Q, grp, h), v_lane16);
+        ld_asm4<1024, (T_NT & 1) != 0>(qb, seg_base(Q, grp, h), v_lane16);
     };
     auto req_head = [&](HeadOps& o, const char* kvc, int h) {  // KV^T fragments and Ksum of head h: L2-hot per-cloud data
         if (T_ABLATE & (16 | 256)) return;
@@ -246,10 +257,10 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         }
         ld_asm4<32>(o.ks, kvc + KV_PLANES_BYTES + 128 * h, v_half16);
     };
-    auto req_x = [&](f32x4 (&xs)[4], int64_t grp, int blk) {
+    auto req_x = [&](f32x4 (&xs)[4], int64_t grp, int blk, auto second) {  // second: the FFN's read (norm2 residual), the last use of the rows
         if (T_ABLATE & (16 | 64)) return;
         if (T_ABLATE & 2048) grp = (int64_t)wave * 32 * SCREAM_D_MODEL;
-        ld_asm4<1024>(xs, seg_base(xres, grp, blk), v_lane16);
+        ld_asm4<1024, (T_NT & (decltype(second)::value ? 4 : 8)) != 0>(xs, seg_base(xres, grp, blk), v_lane16);
     };
     auto pin_head = [&](HeadOps& o) {
 #pragma unroll
@@ -428,13 +439,17 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
             f32x4 (&x_req)[4] = (h & 1) ? xs2 : xs;    // segment h
             if (h > 0) {
                 pin_x(x_prev);
+                if (h - 1 < NSTASH) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) stash[((h - 1) * 4 + a) * 64] = x_prev[a];
+                }
                 if (RIDE) {
                     pin_head(op);
                     pin_x(q_cons);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            req_x(x_req, grp, h);
+            req_x(x_req, grp, h, std::false_type{});
             if (!QF && h + 2 < 8) req_q(q_req, grp, h + 2);  // consumed by stage h + 1 (QF: Q' of every head is in registers already)
             if (h == 0) req_head(op, kvc, 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -678,7 +693,10 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
             if (decltype(first)::value) ring_barrier<0>(); else ring_barrier<PIECES>();
             TMARK2(8, 10);  // T_STAMPS builds: tops of the last two up stages
             __builtin_amdgcn_sched_barrier(0);
-            if (XLOAD >= 0) req_x(xs, grp, XLOAD);
+            if (XLOAD >= 0 && XLOAD < NSTASH) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) xs[a] = stash[(XLOAD * 4 + a) * 64];
+            } else if (XLOAD >= 0) req_x(xs, grp, XLOAD, std::true_type{});
             __builtin_amdgcn_sched_barrier(0);
             const char* wb = smem + (q % T_SLOTS) * STAGE + lane * 16;
             V wf[T_PF][NP];
@@ -861,7 +879,10 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o[k] = acc[b][4 * a + k] * rstd * g4[k] + b4[k];
                         // one contiguous 1 KiB per wave instruction
-                        if ((!(T_ABLATE & (16 | 128)) && !(QF && T_QF_DUMP && T_QF_DUMP < 4)) || o[0] + o[1] + o[2] + o[3] == 123.456f) *reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256) = o;
+                        if ((!(T_ABLATE & (16 | 128)) && !(QF && T_QF_DUMP && T_QF_DUMP < 4)) || o[0] + o[1] + o[2] + o[3] == 123.456f) {
+                            if (T_NT & 2) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256));
+                            else *reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256) = o;
+                        }
                         o2[a2] = o;
                     }
                     if (NQ) {  // B operand of the query stages below
@@ -890,7 +911,10 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
             auto store_chunk = [&](int j) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
-                    if (!(T_ABLATE & (16 | 128)) || oq[a][0] == 123.456f) *reinterpret_cast<f32x4*>(qg + (j * 4 + a) * 256) = oq[a];
+                    if (!(T_ABLATE & (16 | 128)) || oq[a][0] == 123.456f) {
+                        if (T_NT & 2) __builtin_nontemporal_store(oq[a], reinterpret_cast<f32x4*>(qg + (j * 4 + a) * 256));
+                        else *reinterpret_cast<f32x4*>(qg + (j * 4 + a) * 256) = oq[a];
+                    }
             };
             constexpr int PP = (PIECES + NG - 9) / (NG - 8);  // weight pieces per group from group 8 on
             auto stage_q = [&](auto jj) {
