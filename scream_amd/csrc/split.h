@@ -98,6 +98,7 @@ struct SplitH2 {
     static __device__ __forceinline__ f32x16 mfma(vec a, vec b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     template <bool MIRROR = false>
     static __device__ __forceinline__ void products(f32x16& acc, const vec (&x)[2], const vec (&y)[2], const f32x16& c0) {
+        // (round 4: the order x1 y0, x0 y0, x0 y1 -- every product sharing one operand with its predecessor -- measured 0.35 % slower)
         acc = mfma(x[0], y[1], c0);
         acc = mfma(x[1], y[0], acc);
         acc = mfma(x[0], y[0], acc);
