@@ -202,6 +202,8 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
     // (the norm2 residual, FFN): 16 KiB per segment and block, per-wave private (no synchronisation), in the LDS the two-plane rings
     // leave free -- 3/8 of the second read of x never reaches the L2 / HBM (round 4: the review's traffic item)
     constexpr int NSTASH = (NP == 2 && !QF) ? T_STASH : 0;
+    // (ONE object on purpose: with a second __shared__ variable in the kernel hipcc can no longer tell the ring's LDS-DMA writes from other
+    // LDS traffic and puts a vmcnt(0) in front of every fragment read -- 267 of them, every stage 3.4 x slower; met in round 4 with two ints)
     __shared__ __attribute__((aligned(16))) char smem[T_SLOTS * STAGE + 4096 + NSTASH * 16384];  // the ring + the norm parameters + the stash, the ONLY LDS object
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -94,11 +94,11 @@ def run():
             lib = ctypes.CDLL(f)
             ft = lib.scream_layer_tail_f32; ft.restype = ctypes.c_int
             ft.argtypes = [V, V, V, I32, V, V, V, V, V, V, V, V, V, I64, I32, ctypes.POINTER(_lib.TailExpsT), V]
-            pt = lib.scream_pack_tail; pt.restype = ctypes.c_int; pt.argtypes = [V, V, V, V, I32, ctypes.POINTER(_lib.TailExpsT), V, V]
+            pt = lib.scream_pack_tail; pt.restype = ctypes.c_int; pt.argtypes = [V, V, V, V, I32, I32, ctypes.POINTER(_lib.TailExpsT), V, V]
             kf = lib.scream_kv_finalize_image; kf.restype = ctypes.c_int; kf.argtypes = [V, V, V, I64, I32, I32, V, I32, I64, I64, I32, V]
             tb = lib.scream_tail_image_bytes; tb.restype = ctypes.c_int64; tb.argtypes = [I32, I32]
             timg = torch.empty(tb(split, 0), device=dev, dtype=torch.uint8)
-            assert pt(Wm.data_ptr(), W1.data_ptr(), W2.data_ptr(), None, split, ctypes.byref(EX), timg.data_ptr(), st) == 0
+            assert pt(Wm.data_ptr(), W1.data_ptr(), W2.data_ptr(), None, 0, split, ctypes.byref(EX), timg.data_ptr(), st) == 0
             kvi = torch.zeros(n_clouds, lib.scream_kv_image_bytes(), device=dev, dtype=torch.uint8)
             assert kf(part.data_ptr(), crow0.data_ptr(), clen.data_ptr(), 0, 0, n_clouds, kvi.data_ptr(), 1, 0, 0, split, st) == 0
             calls.append(((tag + " " if tag else "") + "fused tail: " + label,
