@@ -449,29 +449,14 @@ __global__ void icp_chunk0_kernel(const int32_t* __restrict__ src_len, int32_t n
 
 // Whole block (256 threads).  Evaluates search e = it - 1 of pair p from its partials; returns (block-uniform) whether the pair
 // stops.  If it goes on, T_sh (LDS) holds T_it = dT . T_e.  `writer`: this block publishes state / done / outputs / T_it.
-// where a pose step finds the partials of search e, T_e and the previous evaluation, and where it leaves its own: global buffers
-// indexed by parity (one launch per iteration) or the LDS of a block that runs the whole schedule (icp_persist_kernel)
-struct PoseMem {
-    const double* part;       // [chunks of the pair][ICP_NP]
-    const float* T_e;         // [16]
-    float* T_next_global;     // [16] or NULL
-    const IcpState* prev;     // evaluation e - 1 (unused at e == 0)
-    IcpState* cur;            // evaluation e
-};
-__device__ __forceinline__ PoseMem pose_mem_global(const IcpArgs& a, int p, int it) {
-    const int e = it - 1;
-    return PoseMem{a.part + (int64_t)(e & 1) * a.part_stride + icp_chunk0(a, p) * ICP_NP, a.Tbuf + ((int64_t)(e & 1) * a.n_pairs + p) * 16,
-                   a.Tbuf + ((int64_t)(it & 1) * a.n_pairs + p) * 16, a.state + (int64_t)((e + 1) & 1) * a.n_pairs + p,
-                   a.state + (int64_t)(e & 1) * a.n_pairs + p};
-}
-__device__ bool icp_pose_step(const IcpArgs& a, int p, int it, bool writer, float* T_sh, const PoseMem& m) {
+__device__ bool icp_pose_step(const IcpArgs& a, int p, int it, bool writer, float* T_sh) {
     __shared__ double grp[ICP_NG][ICP_NP];
     __shared__ double tot[ICP_NP];
     __shared__ float dT_sh[16];
     __shared__ int stop_sh;
     const int e = it - 1, n = a.src_len[p], nb = icp_chunks(n);
-    const double* part = m.part;
-    const float* T_e = m.T_e;
+    const double* part = a.part + (int64_t)(e & 1) * a.part_stride + icp_chunk0(a, p) * ICP_NP;
+    const float* T_e = a.Tbuf + ((int64_t)(e & 1) * a.n_pairs + p) * 16;
     const int tid = threadIdx.x;
     if (tid < ICP_NG * ICP_NP) {
         const int k = tid % ICP_NP, g = tid / ICP_NP;
@@ -491,14 +476,14 @@ __device__ bool icp_pose_step(const IcpArgs& a, int p, int it, bool writer, floa
         const double cnt = tot[0];
         const float fitness = n > 0 ? (float)(cnt / n) : 0.f;
         const float rmse = cnt > 0 ? (float)sqrt(tot[1] / cnt) : 0.f;
-        const IcpState prev = *m.prev;  // evaluation e - 1 (unused at e == 0)
+        const IcpState prev = a.state[(int64_t)((e + 1) & 1) * a.n_pairs + p];  // evaluation e - 1 (unused at e == 0)
         const bool converged = e > 0 && fabsf(prev.fitness - fitness) < a.rel_fitness && fabsf(prev.rmse - rmse) < a.rel_rmse;
         const bool stop = converged || e >= a.max_iter;
         if (tid == 0) {
             stop_sh = stop ? 1 : 0;
             if (writer) {
                 const IcpState o = {fitness, rmse};
-                *m.cur = o;
+                a.state[(int64_t)(e & 1) * a.n_pairs + p] = o;
                 if (a.fit_rmse_out) {
                     a.fit_rmse_out[2 * p + 0] = fitness;
                     a.fit_rmse_out[2 * p + 1] = rmse;
@@ -538,7 +523,7 @@ __device__ bool icp_pose_step(const IcpArgs& a, int p, int it, bool writer, floa
 #pragma unroll
             for (int k = 0; k < 4; ++k) v += dT_sh[i * 4 + k] * T_e[k * 4 + j];
             T_sh[tid] = v;
-            if (writer && m.T_next_global) m.T_next_global[tid] = v;
+            if (writer) a.Tbuf[((int64_t)(it & 1) * a.n_pairs + p) * 16 + tid] = v;
         }
         __syncthreads();
     }
@@ -589,7 +574,7 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(IcpArgs a, const float* _
     const int n = a.src_len[p];
     if (c >= icp_chunks(n)) return;
     if (it > 0) {
-        if (icp_pose_step(a, p, it, c == 0, T_sh, pose_mem_global(a, p, it))) return;
+        if (icp_pose_step(a, p, it, c == 0, T_sh)) return;
     } else {
         if (threadIdx.x < 16) T_sh[threadIdx.x] = a.Tbuf[(int64_t)p * 16 + threadIdx.x];
         __syncthreads();
@@ -617,90 +602,7 @@ __global__ __launch_bounds__(256) void icp_pose_kernel(IcpArgs a, int it) {
     __shared__ float T_sh[16];
     const int p = blockIdx.x;
     if (a.done[p]) return;
-    icp_pose_step(a, p, it, true, T_sh, pose_mem_global(a, p, it));
-}
-
-// ---- the whole schedule of a pair in ONE block (round 4) ----------------------------------------------------------------------
-// One launch per iteration is a chain of up to max_iter + 2 dependent launches; beside a forward whose persistent kernels hold
-// every CU, each link waits for a CU to come free (KITTI harness: 86 % of the rate without ICP).  Here one block of 1024 threads
-// per pair runs evaluate / update / search until the pair stops: four 256-point chunks at a time, the chunk partials (the same
-// values, summed in the same order: the block_sum of a 256-thread block, then icp_pose_step's fixed order over the chunks) in LDS
-// instead of the parity buffers, T and the evaluations in LDS as well (no global location is written and read back inside the
-// launch).  The results are those of the launch-per-iteration schedule bit for bit; the launch holds n_pairs CUs and nothing else.
-// MEASURED AND NOT ADOPTED (opt-in, SCREAM_ICP_PERSIST=1): beside the forward it is far worse -- KITTI harness 283 pairs/s against 577,
-// 3DMatch harness 1 573 against 1 721 (profiles/r04_icp_persist_experiment.txt).  The forward's kernels are persistent grids of one
-// block per CU with a static tile stride; a CU held by an ICP block for milliseconds leaves one of their blocks waiting for a whole
-// round, so every projection / tail launch takes two rounds while any pair is still iterating.  Short launches that slip between the
-// big kernels' blocks are the right shape beside such grids; this kernel is for ICP on an otherwise idle device.
-constexpr int ICP_PERSIST_NT = 1024;
-constexpr int ICP_PERSIST_MAX_CHUNKS = 352;  // 47 872 bytes of partials: clouds up to 90 112 source points (beyond: one launch per iteration)
-
-__global__ __launch_bounds__(ICP_PERSIST_NT) void icp_persist_kernel(IcpArgs a, const float* __restrict__ src_m, const int32_t* __restrict__ r_row0,
-                                                                       const scream_internal::GridParam* __restrict__ gp,
-                                                                       const int32_t* __restrict__ start, const float* __restrict__ sorted_prep,
-                                                                       const int32_t* __restrict__ sorted_idx, float thresh) {
-    extern __shared__ double part_sh[];                 // [chunks][ICP_NP]
-    __shared__ double red[ICP_PERSIST_NT / 64][ICP_NP];  // per wave
-    __shared__ float T_buf[2][16];
-    __shared__ IcpState st_sh[2];
-    const int p = blockIdx.x, tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = tid & 63, wave = tid >> 6;
-    const int n = a.src_len[p], nb = icp_chunks(n);
-    if (tid < 16) T_buf[0][tid] = a.Tbuf[(int64_t)p * 16 + tid];  // T_0 (copied in front of this launch)
-    if (tid < 2) st_sh[tid] = IcpState{0.f, 0.f};
-    __syncthreads();
-    for (int it = 0;; ++it) {
-        float* T_sh = T_buf[it & 1];
-        if (it > 0) {  // evaluation e = it - 1: stops at convergence, and at e == max_iter at the latest
-            const int e = it - 1;
-            const PoseMem m{part_sh, T_buf[e & 1], nullptr, &st_sh[(e + 1) & 1], &st_sh[e & 1]};
-            if (icp_pose_step(a, p, it, true, T_sh, m)) break;
-        }
-        const scream_internal::GridParam g = gp[p];
-        for (int c0 = 0; c0 < nb; c0 += ICP_PERSIST_NT / 256) {
-            const int c = c0 + grp, i = c * 256 + t;
-            float ax = 0.f, ay = 0.f, az = 0.f, d = 0.f, b[3] = {0.f, 0.f, 0.f};
-            uint8_t ok = 0;
-            if (c < nb && i < n) {
-                const int64_t row = (int64_t)a.src_row0[p] + i;
-                const float x = src_m[row * 3 + 0], y = src_m[row * 3 + 1], z = src_m[row * 3 + 2];
-                ax = T_sh[0] * x + T_sh[1] * y + T_sh[2] * z + T_sh[3];  // (the arithmetic of icp_transform_kernel / icp_iter_kernel)
-                ay = T_sh[4] * x + T_sh[5] * y + T_sh[6] * z + T_sh[7];
-                az = T_sh[8] * x + T_sh[9] * y + T_sh[10] * z + T_sh[11];
-                int32_t bi;
-                scream_internal::grid_search_point(g, start + (int64_t)p * (ICP_GRID_CELLS + 1), sorted_prep + (int64_t)r_row0[p] * 4,
-                                                   sorted_idx + r_row0[p], ax, ay, az, thresh, bi, d, ok, b);
-            }
-            // the chunk's partial: icp_store_partial's values and order (block_sum<ICP_NP, 256> of a 256-thread block), per group of four waves
-            double v[ICP_NP];
-#pragma unroll
-            for (int k = 0; k < ICP_NP; ++k) v[k] = 0.0;
-            if (ok) {
-                const float av[3] = {ax, ay, az};
-                v[0] = 1.0;
-                v[1] = (double)d;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    v[2 + k] = (double)av[k];
-                    v[5 + k] = (double)b[k];
-                }
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) v[8 + r * 3 + cc] = (double)av[r] * (double)b[cc];
-            }
-#pragma unroll
-            for (int k = 0; k < ICP_NP; ++k) v[k] = wave_sum_f64(v[k]);
-            __syncthreads();  // red may still be read from the previous round
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < ICP_NP; ++k) red[wave][k] = v[k];
-            }
-            __syncthreads();
-            if (t < ICP_NP && c < nb)
-                part_sh[c * ICP_NP + t] = (red[4 * grp + 0][t] + red[4 * grp + 1][t]) + (red[4 * grp + 2][t] + red[4 * grp + 3][t]);
-        }
-        __syncthreads();
-    }
+    icp_pose_step(a, p, it, true, T_sh);
 }
 
 // SCREAM_ICP_BRUTE=1: the partials of a search done by icp_transform_kernel + scream_nn_search (same per-thread values, same sums)
@@ -861,24 +763,6 @@ extern "C" int scream_icp_p2p_range(const float* src, const float* ref, const in
         }
     }
     const dim3 chunks((max_src_len > 0 ? max_src_len + 255 : 256) / 256, n_pairs);
-    // SCREAM_ICP_PERSIST=1: the whole schedule as ONE launch (icp_persist_kernel), queued by the call that holds iteration 0; the later
-    // pieces of a schedule asked for in pieces find every pair done and have nothing to launch.  NOT the default: measured beside the
-    // forward it halves the KITTI harness rate (see the kernel's comment).
-    const char* persist_env = getenv("SCREAM_ICP_PERSIST");
-    const bool persist = !brute && persist_env && persist_env[0] == '1' && (int)chunks.x <= ICP_PERSIST_MAX_CHUNKS;
-    if (persist) {
-        if (it_begin == 0) {
-            icp_persist_kernel<<<dim3(n_pairs), dim3(ICP_PERSIST_NT), sizeof(double) * ICP_NP * chunks.x, st>>>(
-                a, src_m, ref_row0, reinterpret_cast<const scream_internal::GridParam*>(grid.params), grid.start, grid.sorted_prep, grid.sorted_idx,
-                max_corr_dist * max_corr_dist);
-            SCREAM_LAUNCH_CHECK();
-        }
-        if (done_flags) {
-            e = hipMemcpyAsync(done_flags, a.done, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToDevice, st);
-            if (e != hipSuccess) return (int)e;
-        }
-        return 0;
-    }
     // launch `it` = [evaluate search it - 1, stop or update T] + search it; search max_iter is evaluated by a last pose launch
     // (launch index max_iter + 1).  NOTHING here waits for the device: a pair that has stopped freezes on the device (its
     // blocks return at their first instruction), and a caller that wants to stop LAUNCHING early asks for the schedule in

@@ -175,13 +175,6 @@ def test_gpu_icp_grid_search_equals_brute_force_bitwise(kind, monkeypatch):
     monkeypatch.delenv("SCREAM_ICP_BRUTE", raising=False)
     for a, b in zip(got, want):
         assert torch.equal(a, b), (a, b)
-    # round 4: the whole schedule as ONE launch (SCREAM_ICP_PERSIST=1: icp_persist_kernel, a block per pair, partials in LDS; opt-in, for
-    # ICP on an otherwise idle device) gives the same bits as the launch-per-iteration schedule
-    monkeypatch.setenv("SCREAM_ICP_PERSIST", "1")
-    one = ops.icp_p2p(*args)
-    monkeypatch.delenv("SCREAM_ICP_PERSIST", raising=False)
-    for a, b in zip(got, one):
-        assert torch.equal(a, b), (a, b)
     fit = got[1][:, 0].cpu().numpy()
     assert fit[0] > 0.3 and fit[1] > 0.3   # real registrations: most points have a partner inside the radius
     if kind == "3dmatch":
@@ -207,7 +200,7 @@ def _icp_problem(n_pairs=3, seed0=80, perturb_deg=1.0):
     return batch, s, c, torch.from_numpy(np.stack(T0)).float().to(DEV)
 
 
-def test_gpu_icp_in_pieces_equals_the_whole_schedule_and_never_blocks(monkeypatch):
+def test_gpu_icp_in_pieces_equals_the_whole_schedule_and_never_blocks():
     """scream_icp_p2p_range (round 4): a long schedule enqueued in pieces -- the caller reads the stopped flags between pieces and
     stops launching -- gives bit for bit what the whole schedule gives in one call, whatever the piece sizes; the flags come
     back set exactly for the pairs that have stopped; and the one-call form (max_iter = 1000: a thousand launches, most of them
@@ -218,13 +211,6 @@ def test_gpu_icp_in_pieces_equals_the_whole_schedule_and_never_blocks(monkeypatc
     args = (batch.xyz[: batch.rows_src], batch.xyz[batch.rows_src:], batch.src_row0, batch.src_len_dev, tgt_row0,
             batch.tgt_len_dev, s, c, T0, max(batch.src_len), max(batch.tgt_len), 0.1, 1000)
     want = ops.icp_p2p(*args)  # all 1002 launches
-    monkeypatch.setenv("SCREAM_ICP_PERSIST", "1")  # opt-in: one block per pair runs the whole schedule in the launch of the first piece
-    run = ops.IcpRun(*args)
-    run.advance(1)
-    assert run.all_stopped() and bool(run.flags_host.all())
-    for a, b in zip((run.T, run.fr, run.iters), want):
-        assert torch.equal(a, b)
-    monkeypatch.delenv("SCREAM_ICP_PERSIST", raising=False)
     assert int(want[2].max()) < 200  # (these pairs stop long before the cap: the rest of the schedule ran on frozen pairs)
     for first, piece in ((64, 128), (7, 5), (1, 1)):
         run = ops.IcpRun(*args)
