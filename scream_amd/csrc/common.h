@@ -87,3 +87,7 @@ __device__ __forceinline__ float elu1s(float t, const Elu1Consts& k) {
 __device__ __forceinline__ float elu1(float x) {
     return elu1s(x, Elu1Consts{1.0f, 1.44269502162933349609375f, 1.925963033500011e-08f});
 }
+
+#ifndef SCREAM_MAX_GRID
+#define SCREAM_MAX_GRID 256  // blocks of the persistent grids: one per CU (tuning builds: fewer)
+#endif

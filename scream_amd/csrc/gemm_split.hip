@@ -79,7 +79,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int XBM = 256, XBN = 256, XBK = 32, XTHREADS = 512, XWAVES = 8;
 constexpr int PLANE_BYTES = XBN * XBK * 2;     // 16 KiB; a k-tile stage is SP::NP of them
 constexpr int SLAB_BYTES = XWAVES * 8 * 256 * 4;  // 64 KiB
-constexpr int X_MAX_GRID = 256;
+constexpr int X_MAX_GRID = SCREAM_MAX_GRID;
 
 // s_waitcnt vmcnt(N) lgkmcnt(0) + workgroup barrier: the N youngest vector-memory operations of this wave (the A
 // loads of the k-tile after next) stay in flight across the barrier.

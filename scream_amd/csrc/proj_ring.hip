@@ -54,7 +54,7 @@ namespace {
 
 constexpr int P_KV_ELEMS = (SCREAM_HEAD_DIM + 1) * SCREAM_HEAD_DIM;  // 1056
 constexpr int P_SLAB_BYTES = 4 * P_KV_ELEMS * 4;                      // one K^T V tile + Ksum per wave
-constexpr int P_MAX_GRID = 256;
+constexpr int P_MAX_GRID = SCREAM_MAX_GRID;
 
 struct ProjArgs {
     const float* x;        // fragment-major [M, 256]

@@ -18,7 +18,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int TT = 256;               // threads
 constexpr int T_SLOTS = 3;
-constexpr int T_MAX_GRID = 256;
+constexpr int T_MAX_GRID = SCREAM_MAX_GRID;
 
 // one ring stage: 16 fragments of 1 KiB per operand plane (SplitBf3: 48 KiB, SplitH2: 32 KiB, SplitH1: 16 KiB); a wave issues a quarter of
 // its LDS-DMA pieces
