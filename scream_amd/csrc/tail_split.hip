@@ -365,6 +365,27 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         }
     };
 
+    float dbg6[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // T_QF_DUMP == 6: checksums of the first two applies, stored at the tile's end
+    auto xsum = [&](const V (&ap)[2][NP]) {  // xor of every word of a head's operand planes
+        unsigned c = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) {
+                const f32x4 w = __builtin_bit_cast(f32x4, ap[s2][pl]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c ^= __builtin_bit_cast(unsigned, w[k]);
+            }
+        return __builtin_bit_cast(float, (c & 0x007fffffu) | 0x3f800000u);  // (a float in [1, 2): comparable bit for bit, never a NaN)
+    };
+    auto asum = [&](const f32x16 (&a)[8]) {
+        unsigned c = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) c ^= __builtin_bit_cast(unsigned, a[b][e]);
+        return __builtin_bit_cast(float, (c & 0x007fffffu) | 0x3f800000u);
+    };
     int tile = blockIdx.x;
     int64_t grp = ((int64_t)tile * 128 + wave * 32) * SCREAM_D_MODEL;  // first float of this wave's 32-row group
     const char* kvc = nullptr;
@@ -563,7 +584,20 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
                 ++q;
             };
             stage_qf(HEAD(0)); stage_qf(HEAD(1)); stage_qf(HEAD(2)); stage_qf(HEAD(3));
-            stage_qf(HEAD(4)); stage_qf(HEAD(5)); stage_qf(HEAD(6)); stage_qf(HEAD(7));
+            stage_qf(HEAD(4)); stage_qf(HEAD(5)); stage_qf(HEAD(6));
+            if (T_QF_DUMP == 6) { dbg6[0] = xsum(apA); dbg6[1] = Zs; }
+            stage_qf(HEAD(7));
+            if (T_QF_DUMP == 6) {
+                dbg6[2] = xsum(apB); dbg6[3] = Zs;
+                unsigned c = 0;
+#pragma unroll
+                for (int h = 0; h < 7; ++h)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) c ^= __builtin_bit_cast(unsigned, qall[QF ? h : 0][a][k]);
+                dbg6[4] = __builtin_bit_cast(float, (c & 0x007fffffu) | 0x3f800000u);  // Q' of heads 0 .. 6
+            }
             if (T_QF_DBG & (2 | 64 | 128)) {  // debugging: heads 0 and / or 1 applied in the open behind the query stages (as the first tile's prologue does)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -609,8 +643,9 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         add_x(acc[7], xs2, sc.c1);
 
         TSTAMP(1);  // end of the merge phase
+        if (QF && T_QF_DUMP == 6) dbg6[5] = asum(acc);  // merge + x, in front of norm1
 #if T_QF_DUMP  // debugging: y := Q' of the tile (1) / the merge accumulators in front of norm1 (3); the first up stage below drains
-        if (QF && (T_QF_DUMP < 4 || q_next)) {  // (4 / 5: the same two quantities into q_next, y stored as usual)
+        if (QF && T_QF_DUMP != 6 && (T_QF_DUMP < 4 || q_next)) {  // (4 / 5: the same two quantities into q_next, y stored as usual)
             float* yd = (T_QF_DUMP < 4 ? y : q_next) + grp + lane * 4;
 #pragma unroll
             for (int b = 0; b < 8; ++b)
@@ -662,6 +697,18 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         }
 
         TSTAMP(2);  // end of norm1
+        if (QF && T_QF_DUMP == 6) {
+            unsigned c = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    const f32x4 w = __builtin_bit_cast(f32x4, mp[i][pl]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) c ^= __builtin_bit_cast(unsigned, w[k]);
+                }
+            dbg6[6] = __builtin_bit_cast(float, (c & 0x007fffffu) | 0x3f800000u);  // the planes of m1
+        }
         // ---- FFN; x segments 0 .. 7 (the norm2 residual) are added under the first eight down stages
         f32x16 hT;
         V hpA[2][NP], hpB[2][NP];
@@ -837,6 +884,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         // respect to loads, gemm_split.hip; stage 0 of the next tile starts without a vector-memory wait).
         TSTAMP(3);  // end of the last stage
         VM_WAIT(0);
+        if (QF && T_QF_DUMP == 6) dbg6[7] = asum(acc);  // x + ffn, in front of norm2
         if (!QF && has_next) {
             pin_head(op);
             pin_x(qA);
@@ -847,6 +895,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         TSTAMP(4);  // after the open apply of the next tile's head 1
         // ---- y = LayerNorm2(x + ffn) (the residual is already in the accumulators), stored fragment-major ------------
         V yp[NQ ? 16 : 1][NP];  // NQ: the planes of y
+        unsigned osum_keep = 0, gsum_keep = 0;
         {
             float sum = 0.f;
 #pragma unroll
@@ -868,6 +917,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
             const float* gp = lnp + 512 + 4 * half;
             const float* bp = lnp + 768 + 4 * half;
             float* yg = y + grp + lane * 4;  // (uniform base + lane: the stores below differ by immediates and scalar adds)
+            unsigned osum = 0, gsum = __builtin_bit_cast(unsigned, rstd) ^ (__builtin_bit_cast(unsigned, mean) * 5u);
 #pragma unroll
             for (int b = 0; b < 8; ++b)
 #pragma unroll
@@ -880,6 +930,13 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
                         f32x4 o;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o[k] = acc[b][4 * a + k] * rstd * g4[k] + b4[k];
+                        if (QF && T_QF_DUMP == 6) {  // checksum of the values as computed (slot 4) and of the norm parameters as read (slot 3)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                osum ^= __builtin_bit_cast(unsigned, o[k]);
+                                gsum ^= __builtin_bit_cast(unsigned, g4[k]) ^ (__builtin_bit_cast(unsigned, b4[k]) * 3u);
+                            }
+                        }
                         // one contiguous 1 KiB per wave instruction
                         if ((!(T_ABLATE & (16 | 128)) && !(QF && T_QF_DUMP && T_QF_DUMP < 4)) || o[0] + o[1] + o[2] + o[3] == 123.456f) {
                             if (T_NT & 2) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(yg + (b * 4 + a) * 256));
@@ -892,6 +949,8 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
                         else split8<SP>(o2[0] * sc.s_y, o2[1] * sc.s_y, yp[NQ ? 2 * b + s2 : 0]);
                     }
                 }
+            osum_keep = osum;
+            gsum_keep = gsum;
         }
         if constexpr (NQ) {
             // ---- Q'_next = elu(y . Wq^T) + 1: eight ring stages, chunk j = output features 32 j .. 32 j + 31 (an FFN-up stage with y's
@@ -968,6 +1027,13 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
 #pragma unroll
             for (int k = 0; k < 8; ++k) elu_pair(k, hq[1]);
             store_chunk(7);
+        }
+        if (QF && T_QF_DUMP == 6 && q_next) {
+            float* qd = q_next + grp + lane * 8;
+            dbg6[4] = __builtin_bit_cast(float, (osum_keep & 0x007fffffu) | 0x3f800000u);
+            dbg6[3] = __builtin_bit_cast(float, (gsum_keep & 0x007fffffu) | 0x3f800000u);
+            *reinterpret_cast<f32x4*>(qd) = f32x4{dbg6[0], dbg6[1], dbg6[2], dbg6[3]};
+            *reinterpret_cast<f32x4*>(qd + 4) = f32x4{dbg6[4], dbg6[5], dbg6[6], dbg6[7]};
         }
         TSTAMP(5);  // tile end
         TMARKS_FLUSH();
