@@ -585,10 +585,8 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
             };
             stage_qf(HEAD(0)); stage_qf(HEAD(1)); stage_qf(HEAD(2)); stage_qf(HEAD(3));
             stage_qf(HEAD(4)); stage_qf(HEAD(5)); stage_qf(HEAD(6));
-            if (T_QF_DUMP == 6) { dbg6[0] = xsum(apA); dbg6[1] = Zs; }
             stage_qf(HEAD(7));
             if (T_QF_DUMP == 6) {
-                dbg6[2] = xsum(apB); dbg6[3] = Zs;
                 unsigned c = 0;
 #pragma unroll
                 for (int h = 0; h < 7; ++h)
@@ -643,7 +641,6 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         add_x(acc[7], xs2, sc.c1);
 
         TSTAMP(1);  // end of the merge phase
-        if (QF && T_QF_DUMP == 6) dbg6[5] = asum(acc);  // merge + x, in front of norm1
 #if T_QF_DUMP  // debugging: y := Q' of the tile (1) / the merge accumulators in front of norm1 (3); the first up stage below drains
         if (QF && T_QF_DUMP != 6 && (T_QF_DUMP < 4 || q_next)) {  // (4 / 5: the same two quantities into q_next, y stored as usual)
             float* yd = (T_QF_DUMP < 4 ? y : q_next) + grp + lane * 4;
@@ -707,7 +704,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
 #pragma unroll
                     for (int k = 0; k < 4; ++k) c ^= __builtin_bit_cast(unsigned, w[k]);
                 }
-            dbg6[6] = __builtin_bit_cast(float, (c & 0x007fffffu) | 0x3f800000u);  // the planes of m1
+            (void)c;
         }
         // ---- FFN; x segments 0 .. 7 (the norm2 residual) are added under the first eight down stages
         f32x16 hT;
@@ -884,7 +881,7 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         // respect to loads, gemm_split.hip; stage 0 of the next tile starts without a vector-memory wait).
         TSTAMP(3);  // end of the last stage
         VM_WAIT(0);
-        if (QF && T_QF_DUMP == 6) dbg6[7] = asum(acc);  // x + ffn, in front of norm2
+        if (QF && T_QF_DUMP == 6) dbg6[3] = asum(acc);  // x + ffn, in front of norm2
         if (!QF && has_next) {
             pin_head(op);
             pin_x(qA);
@@ -902,6 +899,10 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
             for (int b = 0; b < 8; ++b)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) sum += acc[b][e];
+            if (QF && T_QF_DUMP == 6) {  // the lane's own partial sum, the partner's as exchanged, and a second exchange of the same value
+                const float p1 = __shfl_xor(sum, 32), p2 = __shfl_xor(sum, 32);
+                dbg6[5] = sum; dbg6[6] = p1; dbg6[7] = (p1 == p2) ? 1.0f : 2.0f;
+            }
             sum += __shfl_xor(sum, 32);
             const float mean = sum * (1.0f / 256.0f);
             float var = 0.f;
@@ -917,7 +918,8 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
             const float* gp = lnp + 512 + 4 * half;
             const float* bp = lnp + 768 + 4 * half;
             float* yg = y + grp + lane * 4;  // (uniform base + lane: the stores below differ by immediates and scalar adds)
-            unsigned osum = 0, gsum = __builtin_bit_cast(unsigned, rstd) ^ (__builtin_bit_cast(unsigned, mean) * 5u);
+            unsigned osum = 0, gsum = 0;
+            if (QF && T_QF_DUMP == 6) { dbg6[0] = mean; dbg6[1] = rstd; dbg6[2] = var; }
 #pragma unroll
             for (int b = 0; b < 8; ++b)
 #pragma unroll
@@ -1031,7 +1033,6 @@ __global__ __launch_bounds__(TT, 1) void tail_kernel(const float* __restrict__ Q
         if (QF && T_QF_DUMP == 6 && q_next) {
             float* qd = q_next + grp + lane * 8;
             dbg6[4] = __builtin_bit_cast(float, (osum_keep & 0x007fffffu) | 0x3f800000u);
-            dbg6[3] = __builtin_bit_cast(float, (gsum_keep & 0x007fffffu) | 0x3f800000u);
             *reinterpret_cast<f32x4*>(qd) = f32x4{dbg6[0], dbg6[1], dbg6[2], dbg6[3]};
             *reinterpret_cast<f32x4*>(qd + 4) = f32x4{dbg6[4], dbg6[5], dbg6[6], dbg6[7]};
         }

@@ -105,7 +105,7 @@ while time.time() - t0 < secs:
             if os.environ.get("QF_DUMP6") == "1":  # words 0-4 of every lane's 8: xor(apA), Zs(head 0), xor(apB), Zs(head 1), xor(Q' heads 0-6)
                 a, b = r1[1].view(-1, 8), r2[1].view(-1, 8)
                 ne = (a != b)
-                print("  y differs in %d rows; checksum words that differ anywhere: %s (0 planes of head 0, 1 its Z, 2 planes of head 1, 3 mean / rstd / gamma2 / beta2 as read, 4 y as computed, 5 merge accumulators, 6 planes of m1, 7 FFN accumulators); lanes %d"
+                print("  y differs in %d rows; checksum words that differ anywhere: %s (0 mean of norm2, 1 rstd, 2 var, 3 xor of the FFN accumulators in front of norm2, 4 y as computed, 5 the lane's partial sum, 6 the partner's as exchanged, 7 two exchanges agree); lanes %d"
                       % (len(ry), ne.any(dim=0).nonzero().flatten().tolist(), int(ne.any(dim=1).sum())), flush=True)
                 continue
             print("  y differs in %d rows; the dumped intermediate in %d rows, %d features, chunks %s; rows of y not among them: %d"
